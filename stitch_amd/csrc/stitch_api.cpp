@@ -1,0 +1,598 @@
+// C ABI of the MI355X-native `stitch align` hot path (include/stitch_gpu.h).
+//
+// Per batch this file does what Aligners::align does per read (fg-stitch-lib/src/align/aligners/mod.rs:237-340):
+//   pass 1  one DP job per distinct read  -> fill kernel -> fix-up + walk kernel (primary chain, or one candidate
+//           chain per end contig when --suboptimal)
+//   host    remove_clipping, traceback_all's end-contig selection, realign_origin planning (mod.rs:442-553)
+//   pass 2  the rotated-read re-alignments of circular contigs as further DP jobs on the contig subset of the chain
+//   host    accept / split_at_y, suboptimal filter, result arena
+// There is no CPU DP in this library: without a working HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/stitch_gpu.h"
+#include "dp_core.h"
+#include "host_align.h"
+#include "walk_core.h"
+
+namespace stitch {
+struct FillShared {
+    const int32_t* S0; const uint32_t* Slen0; const int32_t* Sn0; const uint8_t* SnSet0; const uint8_t* Smove0;
+    const uint32_t* lx0; const JumpBase* base0;
+};
+void launch_fill(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillShared& sh, hipStream_t stream);
+void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, hipStream_t stream);
+constexpr uint32_t TILE_ROWS = 256;   // 64 lanes x R=4 rows; contig row blocks are padded to this
+}  // namespace stitch
+
+using namespace stitch;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(STITCH_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct stitch_index {
+    std::vector<std::string> names;
+    std::vector<std::vector<uint8_t>> seqs;     // upper-cased forward strands
+};
+
+struct Aligner { uint32_t target; bool fwd; uint32_t m, troff, seqoff; int32_t opp; };
+
+struct Job {                                     // one full jump DP
+    std::vector<uint8_t> y;                      // upper-cased query
+    std::vector<uint32_t> act;                   // active aligner ids, ascending (== aligner order)
+    int mode = 0;                                // 0 traceback, 1 traceback_all candidates, 2 traceback_from(from)
+    uint32_t from = 0;
+    // results
+    std::vector<HAln> chains;                    // mode 1: one per active contig (status per chain below)
+    std::vector<uint32_t> status;
+};
+
+struct stitch_ctx {
+    int device = 0;
+    stitch_opts opts{};
+    DpParams P{};
+    std::vector<TargetInfo> targets;
+    std::vector<Aligner> al;
+    uint32_t C = 0, T = 0, RtotT = 0, max_m = 0;
+    hipStream_t stream = nullptr;
+    // device, context lifetime
+    uint8_t* d_xseq = nullptr; int32_t* d_S0 = nullptr; uint32_t* d_Slen0 = nullptr; int32_t* d_Sn0 = nullptr;
+    uint8_t* d_SnSet0 = nullptr; uint8_t* d_Smove0 = nullptr; uint8_t* d_Imove0 = nullptr; uint32_t* d_lx0 = nullptr;
+    JumpBase* d_base0 = nullptr;
+    // device arena reused across launches
+    uint8_t* arena = nullptr; size_t arena_bytes = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // results of the last batch
+    std::vector<stitch_read_result> rr; std::vector<stitch_chain> chains; std::vector<stitch_op> ops;
+    std::vector<std::vector<HAln>> per_read;     // for stitch_format_sam
+    stitch_timing tm{};
+    size_t mem_limit = 0;                        // optional cap on arena bytes (STITCH_ARENA_BYTES), for tests
+};
+
+static std::vector<uint8_t> revcomp(const std::vector<uint8_t>& s) {             // util/dna.rs:5-41
+    static const char* A = "AGCTYRWSKMDVHBN"; static const char* B = "TCGARYWSMKHBDVN";
+    uint8_t comp[256]; for (int v = 0; v < 256; ++v) comp[v] = (uint8_t)v;
+    for (int k = 0; k < 15; ++k) { comp[(uint8_t)A[k]] = (uint8_t)B[k]; comp[(uint8_t)A[k] + 32] = (uint8_t)(B[k] + 32); }
+    std::vector<uint8_t> r(s.size());
+    for (size_t k = 0; k < s.size(); ++k) r[k] = comp[s[s.size() - 1 - k]];
+    return r;
+}
+
+template <typename T> static int upload(T** dst, const std::vector<T>& src) {
+    HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(16, src.size() * sizeof(T))));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return STITCH_OK;
+}
+
+extern "C" {
+
+const char* stitch_last_error(void) { return g_err.c_str(); }
+const char* stitch_version(void) { return "stitch_amd 0.1 (gfx950)"; }
+
+void stitch_opts_default(stitch_opts* o) {       // Builder defaults, aligners/mod.rs:65-116
+    memset(o, 0, sizeof(*o));
+    o->mode = 0; o->match_score = 1; o->mismatch_score = -4; o->gap_open = -6; o->gap_extend = -2;
+    o->jump_same = o->jump_opposite = o->jump_inter = -10;
+    o->circular_slop = 20; o->pre_align_min_score = 100; o->pre_align_subset_contigs = 1; o->kmer_size = 12; o->band_width = 50;
+    o->suboptimal_pct = 20.0f; o->filter_secondary_pct = 10.0f;
+}
+
+int stitch_index_build(const char* const* names, const uint8_t* const* seqs, const uint32_t* lens, uint32_t n_contigs,
+                       stitch_index** out) {
+    if (!out || !names || !seqs || !lens) return fail(STITCH_EINVAL, "null argument");
+    if (n_contigs == 0) return fail(STITCH_EINVAL, "Found no sequences in the FASTA");            // target_seq.rs:107
+    auto idx = std::make_unique<stitch_index>();
+    for (uint32_t k = 0; k < n_contigs; ++k) {
+        if (lens[k] == 0) return fail(STITCH_EINVAL, "empty contig");
+        if (lens[k] > 134217727u) return fail(STITCH_EINVAL, "contig longer than 2^27-1 bp (packed_length_cell.rs:108-110)");
+        idx->names.emplace_back(names[k]);
+        std::vector<uint8_t> s(seqs[k], seqs[k] + lens[k]);
+        for (auto& b : s) if (b >= 'a' && b <= 'z') b = (uint8_t)(b - 32);                         // target_seq.rs:111-115
+        idx->seqs.push_back(std::move(s));
+    }
+    *out = idx.release();
+    return STITCH_OK;
+}
+
+uint32_t stitch_index_n_contigs(const stitch_index* i) { return i ? (uint32_t)i->names.size() : 0; }
+void stitch_index_destroy(stitch_index* i) { delete i; }
+
+// blob: "STIX" u32 version u32 T, then per contig: u32 name_len, name, u32 seq_len, seq
+int stitch_index_serialize(const stitch_index* idx, void* buf, size_t* len) {
+    if (!idx || !len) return fail(STITCH_EINVAL, "null argument");
+    size_t need = 12;
+    for (size_t k = 0; k < idx->names.size(); ++k) need += 8 + idx->names[k].size() + idx->seqs[k].size();
+    if (!buf) { *len = need; return STITCH_OK; }
+    if (*len < need) { *len = need; return fail(STITCH_EINVAL, "buffer too small"); }
+    uint8_t* p = (uint8_t*)buf;
+    auto put32 = [&](uint32_t v) { memcpy(p, &v, 4); p += 4; };
+    memcpy(p, "STIX", 4); p += 4; put32(1); put32((uint32_t)idx->names.size());
+    for (size_t k = 0; k < idx->names.size(); ++k) {
+        put32((uint32_t)idx->names[k].size()); memcpy(p, idx->names[k].data(), idx->names[k].size()); p += idx->names[k].size();
+        put32((uint32_t)idx->seqs[k].size()); memcpy(p, idx->seqs[k].data(), idx->seqs[k].size()); p += idx->seqs[k].size();
+    }
+    *len = need;
+    return STITCH_OK;
+}
+
+int stitch_index_deserialize(const void* buf, size_t len, stitch_index** out) {
+    if (!buf || !out || len < 12 || memcmp(buf, "STIX", 4) != 0) return fail(STITCH_EINVAL, "not a stitch index blob");
+    const uint8_t* p = (const uint8_t*)buf; const uint8_t* end = p + len; p += 4;
+    auto get32 = [&](uint32_t& v) { if (p + 4 > end) return false; memcpy(&v, p, 4); p += 4; return true; };
+    uint32_t ver, T;
+    if (!get32(ver) || ver != 1 || !get32(T) || T == 0) return fail(STITCH_EINVAL, "bad index blob header");
+    auto idx = std::make_unique<stitch_index>();
+    for (uint32_t k = 0; k < T; ++k) {
+        uint32_t nl, sl;
+        if (!get32(nl) || p + nl > end) return fail(STITCH_EINVAL, "truncated index blob");
+        idx->names.emplace_back((const char*)p, nl); p += nl;
+        if (!get32(sl) || p + sl > end) return fail(STITCH_EINVAL, "truncated index blob");
+        idx->seqs.emplace_back(p, p + sl); p += sl;
+    }
+    *out = idx.release();
+    return STITCH_OK;
+}
+
+void stitch_ctx_destroy(stitch_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void* ptrs[] = {c->d_xseq, c->d_S0, c->d_Slen0, c->d_Sn0, c->d_SnSet0, c->d_Smove0, c->d_Imove0, c->d_lx0, c->d_base0, c->arena};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_opts* o, stitch_ctx** out) {
+    if (!idx || !o || !out) return fail(STITCH_EINVAL, "null argument");
+    if (o->mode < 0 || o->mode > 3) return fail(STITCH_EINVAL, "Custom alignment mode not supported");      // mod.rs:129
+    // the reference's constructor asserts (single_contig_aligner.rs:638-655, scoring.rs:36-73)
+    if (o->gap_open > 0) return fail(STITCH_EINVAL, "gap_open can't be positive");
+    if (o->gap_extend > 0) return fail(STITCH_EINVAL, "gap_extend can't be positive");
+    if (o->jump_same > 0 || o->jump_opposite > 0 || o->jump_inter > 0) return fail(STITCH_EINVAL, "jump scores can't be positive");
+    if (o->pre_align) return fail(STITCH_EINVAL, "pre_align (bio banded pre-filter) is not implemented in this build; see DESIGN.md");
+    const uint32_t T = (uint32_t)idx->names.size();
+    const uint32_t C = T * (o->double_strand ? 2u : 1u);
+    if (C > 255) return fail(STITCH_EINVAL, "more than 255 contig-strands (packed_length_cell.rs:112-114)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(STITCH_EDEVICE, "no HIP device: this library has no CPU path");
+    if (device_ordinal < 0 || device_ordinal >= ndev) return fail(STITCH_EDEVICE, "bad device ordinal");
+    HIP_TRY(hipSetDevice(device_ordinal));
+
+    std::unique_ptr<stitch_ctx, void (*)(stitch_ctx*)> c(new stitch_ctx(), stitch_ctx_destroy);
+    c->device = device_ordinal; c->opts = *o; c->T = T; c->C = C;
+    DpParams& P = c->P;
+    P.match = o->match_score; P.mismatch = o->mismatch_score; P.gap_open = o->gap_open; P.gap_extend = o->gap_extend;
+    P.jump_same = o->jump_same; P.jump_opp = o->jump_opposite; P.jump_inter = o->jump_inter; P.circular = o->circular ? 1 : 0;
+    switch (o->mode) {                                        // Options::clipping, mod.rs:123-131
+        case 0: P.xclip_prefix = P.xclip_suffix = P.yclip_prefix = P.yclip_suffix = 0; break;
+        case 1: P.xclip_prefix = P.xclip_suffix = MIN_SCORE; P.yclip_prefix = P.yclip_suffix = 0; break;
+        case 2: P.xclip_prefix = P.xclip_suffix = 0; P.yclip_prefix = P.yclip_suffix = MIN_SCORE; break;
+        default: P.xclip_prefix = P.xclip_suffix = P.yclip_prefix = P.yclip_suffix = MIN_SCORE; break;
+    }
+    for (uint32_t t = 0; t < T; ++t) c->targets.push_back(TargetInfo{idx->names[t], (uint32_t)idx->seqs[t].size()});
+
+    // aligners: forward strands 0..T-1, then reverse complements T..2T-1 (build_aligners, mod.rs:182-205)
+    std::vector<uint8_t> xseq;
+    uint32_t troff = 0;
+    for (uint32_t a = 0; a < C; ++a) {
+        const uint32_t t = a % T; const bool fwd = a < T;
+        Aligner al; al.target = t; al.fwd = fwd; al.m = (uint32_t)idx->seqs[t].size(); al.troff = troff; al.seqoff = (uint32_t)xseq.size();
+        al.opp = -1;
+        std::vector<uint8_t> s = fwd ? idx->seqs[t] : revcomp(idx->seqs[t]);
+        xseq.insert(xseq.end(), s.begin(), s.end());
+        while (xseq.size() % TILE_ROWS) xseq.push_back(0);     // tile loads may run past m
+        troff += (al.m + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+        c->max_m = std::max(c->max_m, al.m);
+        c->al.push_back(al);
+    }
+    c->RtotT = troff;
+    // opposite strands: same NAME and different strand, first match wins (multi_contig_aligner.rs:241-262)
+    for (uint32_t a = 0; a < C; ++a) {
+        if (c->al[a].opp >= 0) continue;
+        for (uint32_t b = a + 1; b < C; ++b)
+            if (c->targets[c->al[a].target].name == c->targets[c->al[b].target].name && c->al[a].fwd != c->al[b].fwd) {
+                c->al[a].opp = (int32_t)b; c->al[b].opp = (int32_t)a;
+            }
+    }
+    // column 0 (init_matrices) per aligner + get_jump_info over column 0
+    std::vector<int32_t> S0(troff, MIN_SCORE), Sn0(troff, MIN_SCORE); std::vector<uint32_t> Slen0(troff, 0), lx0(C, 0);
+    std::vector<uint8_t> SnSet0(troff, 0), Smove0(troff, 0), Imove0(troff, 0); std::vector<JumpBase> base0(C);
+    std::vector<Col0Row> rows;
+    for (uint32_t a = 0; a < C; ++a) {
+        const Aligner& al = c->al[a];
+        rows.resize(al.m);
+        lx0[a] = col0_init(P, al.m, rows.data());
+        JumpBase b; b.score = 0; b.from = 0; b.len = 0 + 1;                    // row 0: S[0][0] = 0, cell(0,0).S.len = 0
+        for (uint32_t i = 1; i <= al.m; ++i) {
+            const Col0Row& r = rows[i - 1]; const uint32_t x = al.troff + i - 1;
+            S0[x] = r.S; Slen0[x] = r.Slen; Sn0[x] = r.Sn; SnSet0[x] = r.sn_set; Smove0[x] = r.Smove; Imove0[x] = r.Imove;
+            if (b.score < r.S) { b.score = r.S; b.from = i; b.len = r.Slen + 1; }   // strict <: lowest row wins (:683)
+        }
+        base0[a] = b;
+    }
+    int rc;
+    if ((rc = upload(&c->d_xseq, xseq)) || (rc = upload(&c->d_S0, S0)) || (rc = upload(&c->d_Slen0, Slen0)) || (rc = upload(&c->d_Sn0, Sn0)) ||
+        (rc = upload(&c->d_SnSet0, SnSet0)) || (rc = upload(&c->d_Smove0, Smove0)) || (rc = upload(&c->d_Imove0, Imove0)) ||
+        (rc = upload(&c->d_lx0, lx0)) || (rc = upload(&c->d_base0, base0))) return rc;
+    HIP_TRY(hipStreamCreate(&c->stream));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    if (const char* lim = getenv("STITCH_ARENA_BYTES")) c->mem_limit = (size_t)strtoull(lim, nullptr, 10);
+    *out = c.release();
+    return STITCH_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Running a list of DP jobs on the device
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct JobLayout {
+    uint32_t n, nact, Rj, slots, ops_cap;
+    size_t off_S, off_Slen, off_D, off_Dlen, off_Sn, off_SnLen, off_Ly, off_Ival, off_Ilen, off_SidxF, off_SfromF, off_SmoveF, off_ImoveF,
+        off_tb, off_Lx, off_jti, off_jtf, off_Sm, off_Lm, off_y, off_act, off_opp, off_cd, off_hdr, off_ops, bytes;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
+    JobLayout L{};
+    L.n = (uint32_t)jb.y.size(); L.nact = (uint32_t)jb.act.size();
+    uint32_t R = 0; for (uint32_t a : jb.act) R += (c.al[a].m + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+    L.Rj = R;
+    L.slots = jb.mode == 1 ? L.nact : 1;
+    L.ops_cap = 2 * L.n + 2 * c.max_m + 64;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    L.off_S = take(4ull * R); L.off_Slen = take(4ull * R); L.off_D = take(4ull * R); L.off_Dlen = take(4ull * R);
+    L.off_Sn = take(4ull * R); L.off_SnLen = take(4ull * R); L.off_Ly = take(4ull * R);
+    L.off_Ival = take(4ull * R); L.off_Ilen = take(4ull * R); L.off_SidxF = take(4ull * R); L.off_SfromF = take(4ull * R);
+    L.off_SmoveF = take(R); L.off_ImoveF = take(R);
+    L.off_tb = take((size_t)L.n * R);
+    L.off_Lx = take(4ull * c.C * (L.n + 1)); L.off_jti = take(4ull * c.C * (L.n + 1)); L.off_jtf = take(4ull * c.C * (L.n + 1));
+    L.off_Sm = take(4ull * c.C); L.off_Lm = take(4ull * c.C);
+    L.off_y = take(L.n); L.off_act = take(4ull * L.nact); L.off_opp = take(4ull * c.C); L.off_cd = take(sizeof(ContigDesc) * (size_t)c.C);
+    L.off_hdr = take(sizeof(ChainHdr) * (size_t)L.slots); L.off_ops = take(sizeof(OpRec) * (size_t)L.slots * L.ops_cap);
+    L.bytes = o;
+    return L;
+}
+
+int pick_waves(uint32_t nact) {                    // fewest rounds of contigs per column, then fewest waves
+    int best_w = 1, best_rounds = (int)nact;
+    for (int w = 1; w <= 8; ++w) { int r = ((int)nact + w - 1) / w; if (r < best_rounds) { best_rounds = r; best_w = w; } }
+    return best_w;
+}
+
+int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
+    if (jobs.empty()) return STITCH_OK;
+    HIP_TRY(hipSetDevice(c.device));
+    std::vector<JobLayout> lay(jobs.size());
+    size_t max_job = 0;
+    for (size_t k = 0; k < jobs.size(); ++k) { lay[k] = layout_job(c, jobs[k]); max_job = std::max(max_job, lay[k].bytes); }
+    // arena: as much of the free memory as useful, at least one job
+    size_t want = 0; for (auto& L : lay) want += L.bytes + sizeof(JobView) + 256;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = (size_t)((free_b + c.arena_bytes) * 0.90);
+    if (c.mem_limit) budget = std::min(budget, c.mem_limit);
+    if (max_job + (1 << 20) > budget) return fail(STITCH_ENOMEM, "one read needs " + std::to_string(max_job >> 20) + " MiB of device memory; only " + std::to_string(budget >> 20) + " MiB usable");
+    size_t arena_need = std::min(want + (1 << 20), budget);
+    if (arena_need > c.arena_bytes) {
+        if (c.arena) { HIP_TRY(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&c.arena, arena_need));
+        c.arena_bytes = arena_need;
+    }
+    FillShared sh{c.d_S0, c.d_Slen0, c.d_Sn0, c.d_SnSet0, c.d_Smove0, c.d_lx0, c.d_base0};
+
+    size_t k0 = 0;
+    while (k0 < jobs.size()) {
+        // greedy pack of consecutive jobs into the arena
+        size_t k1 = k0, used = 0;
+        const size_t view_room = 1 << 20;
+        while (k1 < jobs.size() && used + lay[k1].bytes + view_room <= c.arena_bytes && (k1 - k0) < 4096) { used += lay[k1].bytes; ++k1; }
+        if (k1 == k0) return fail(STITCH_ENOMEM, "arena too small for one job");
+        const uint32_t nj = (uint32_t)(k1 - k0);
+        std::vector<JobView> views(nj); std::vector<WalkArgs> wargs(nj);
+        std::vector<size_t> base(nj);
+        int waves = 1;
+        auto t_h2d0 = std::chrono::steady_clock::now();
+        size_t o = 0;
+        for (uint32_t q = 0; q < nj; ++q) {
+            const Job& jb = jobs[k0 + q]; const JobLayout& L = lay[k0 + q];
+            base[q] = o; uint8_t* B = c.arena + o; o += L.bytes;
+            waves = std::max(waves, pick_waves(L.nact));
+            // per-job tables
+            std::vector<ContigDesc> cd(c.C); std::vector<int32_t> opp(c.C, -1); std::vector<uint8_t> isact(c.C, 0);
+            for (uint32_t a : jb.act) isact[a] = 1;
+            uint32_t roff = 0;
+            for (uint32_t a = 0; a < c.C; ++a) {
+                ContigDesc d{}; d.m = c.al[a].m; d.troff = c.al[a].troff; d.seqoff = c.al[a].seqoff; d.target = c.al[a].target; d.opp = c.al[a].opp;
+                d.roff = 0;
+                if (isact[a]) { d.roff = roff; roff += (d.m + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS; }
+                cd[a] = d;
+                // the opposite strand only counts when it is part of the current subset (multi_contig_aligner.rs:241-262)
+                if (isact[a] && c.al[a].opp >= 0 && isact[c.al[a].opp]) opp[a] = c.al[a].opp;
+            }
+            HIP_TRY(hipMemcpyAsync(B + L.off_y, jb.y.data(), L.n, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(B + L.off_act, jb.act.data(), 4ull * L.nact, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(B + L.off_opp, opp.data(), 4ull * c.C, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(B + L.off_cd, cd.data(), sizeof(ContigDesc) * (size_t)c.C, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipStreamSynchronize(c.stream));            // cd/opp are stack vectors
+            JobView& V = views[q];
+            V.P = c.P; V.n = L.n; V.C = c.C; V.nact = L.nact; V.Rtot = L.Rj;
+            V.act = (const uint32_t*)(B + L.off_act); V.opp_act = (const int32_t*)(B + L.off_opp); V.cd = (const ContigDesc*)(B + L.off_cd);
+            V.xseq = c.d_xseq; V.y = B + L.off_y;
+            V.S = (int32_t*)(B + L.off_S); V.Slen = (uint32_t*)(B + L.off_Slen); V.D = (int32_t*)(B + L.off_D); V.Dlen = (uint32_t*)(B + L.off_Dlen);
+            V.Sn = (int32_t*)(B + L.off_Sn); V.SnLen = (uint32_t*)(B + L.off_SnLen); V.Ly = (uint32_t*)(B + L.off_Ly);
+            V.tb = B + L.off_tb; V.Lx = (uint32_t*)(B + L.off_Lx); V.jt_idx = (uint32_t*)(B + L.off_jti); V.jt_from = (uint32_t*)(B + L.off_jtf);
+            V.Ival = (int32_t*)(B + L.off_Ival); V.Ilen = (uint32_t*)(B + L.off_Ilen); V.SmoveF = B + L.off_SmoveF;
+            V.SidxF = (uint32_t*)(B + L.off_SidxF); V.SfromF = (uint32_t*)(B + L.off_SfromF); V.ImoveF = B + L.off_ImoveF;
+            V.Smove0 = c.d_Smove0; V.Imove0 = c.d_Imove0; V.Slen0 = c.d_Slen0;
+            V.Sm = (int32_t*)(B + L.off_Sm); V.Lm = (uint32_t*)(B + L.off_Lm);
+            WalkArgs& A = wargs[q]; A.hdr = (ChainHdr*)(B + L.off_hdr); A.ops = (OpRec*)(B + L.off_ops); A.ops_cap = L.ops_cap; A.mode = jb.mode; A.from = jb.from; A.pad = 0;
+            c.tm.cells += (uint64_t)L.n * [&] { uint64_t s = 0; for (uint32_t a : jb.act) s += c.al[a].m; return s; }();
+        }
+        // launch-level tables live after the jobs
+        uint8_t* tail = c.arena + align_up(o, 256);
+        JobView* d_views = (JobView*)tail; tail += align_up(sizeof(JobView) * nj, 256);
+        WalkArgs* d_wargs = (WalkArgs*)tail; tail += align_up(sizeof(WalkArgs) * nj, 256);
+        if ((size_t)(tail - c.arena) > c.arena_bytes) return fail(STITCH_EINTERNAL, "arena overflow");
+        HIP_TRY(hipMemcpyAsync(d_views, views.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemcpyAsync(d_wargs, wargs.data(), sizeof(WalkArgs) * nj, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        c.tm.h2d_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h2d0).count();
+
+        // Kernel 1 and 2, timed with events on the stream they run on
+        HIP_TRY(hipEventRecord(c.ev[0], c.stream));
+        launch_fill(d_views, nj, waves, sh, c.stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c.ev[1], c.stream));
+        launch_fixup_walk(d_views, d_wargs, nj, c.stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c.ev[2], c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c.ev[0], c.ev[1])); c.tm.fill_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, c.ev[1], c.ev[2])); c.tm.walk_ms += ms;
+        c.tm.launches += 1; c.tm.jobs += nj;
+
+        // download chains
+        auto t_d2h0 = std::chrono::steady_clock::now();
+        for (uint32_t q = 0; q < nj; ++q) {
+            Job& jb = jobs[k0 + q]; const JobLayout& L = lay[k0 + q]; uint8_t* B = c.arena + base[q];
+            std::vector<ChainHdr> hdrs(L.slots);
+            HIP_TRY(hipMemcpy(hdrs.data(), B + L.off_hdr, sizeof(ChainHdr) * (size_t)L.slots, hipMemcpyDeviceToHost));
+            jb.chains.assign(L.slots, HAln()); jb.status.assign(L.slots, 0);
+            for (uint32_t s = 0; s < L.slots; ++s) {
+                const ChainHdr& H = hdrs[s];
+                jb.status[s] = H.status;
+                if (H.status >= 2) return fail(STITCH_EINTERNAL, "traceback failed on the device (status " + std::to_string(H.status) + ")");
+                if (H.status == 1) continue;
+                HAln& a = jb.chains[s];
+                a.score = H.score; a.xstart = H.xstart; a.xend = H.xend; a.ystart = H.ystart; a.yend = H.yend; a.xlen = H.xlen; a.ylen = H.ylen;
+                a.start_contig_idx = H.start_contig_idx; a.end_contig_idx = H.end_contig_idx; a.length = H.length;
+                a.ops.resize(H.n_ops);
+                static_assert(sizeof(OpRec) == sizeof(stitch_op), "op layout");
+                if (H.n_ops) HIP_TRY(hipMemcpy(a.ops.data(), B + L.off_ops + sizeof(OpRec) * (size_t)s * L.ops_cap, sizeof(OpRec) * (size_t)H.n_ops, hipMemcpyDeviceToHost));
+            }
+        }
+        c.tm.d2h_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d2h0).count();
+        k0 = k1;
+    }
+    return STITCH_OK;
+}
+
+// traceback_all's selection loop over per-end-contig candidate chains (traceback/mod.rs:152-217)
+std::vector<HAln> select_all(const stitch_ctx& c, const Job& jb) {
+    std::vector<HAln> out;
+    std::vector<uint8_t> consider(c.C, 0), seen(c.C, 0);
+    for (uint32_t a : jb.act) consider[a] = 1;
+    size_t n_consider = jb.act.size(), n_seen = 0, guard = 0;
+    auto mark = [&](uint32_t a) { if (a < c.C && consider[a] && !seen[a]) { seen[a] = 1; ++n_seen; } };
+    while (n_seen < n_consider) {
+        if (++guard > 4 * n_consider + 16) break;
+        size_t pick = 0; int32_t score = MIN_SCORE; uint32_t alen = 0;
+        for (size_t k = 0; k < jb.act.size(); ++k) {
+            if (seen[jb.act[k]]) continue;
+            // S[n%2][m] and cell(m,n).S.len of aligner k: carried in its candidate chain
+            int32_t s = jb.chains[k].score; uint32_t l = jb.chains[k].length;
+            if (s > score || (s == score && l > alen)) { pick = k; score = s; alen = l; }
+        }
+        if (jb.status[pick] == 1) { mark(jb.act[pick]); continue; }
+        const HAln& a = jb.chains[pick];
+        mark(a.start_contig_idx); mark(a.end_contig_idx);
+        for (const stitch_op& op : a.ops) if (op.kind == OP_XJUMP) mark(op.contig);
+        out.push_back(a);
+    }
+    return out;
+}
+
+struct RealignPlan {                                // realign_origin (mod.rs:442-553) for one chain
+    bool needed = false;
+    HAln original;
+    std::vector<uint32_t> subset;
+    struct Step { size_t job; uint32_t contig; uint32_t y_pivot; };
+    std::vector<Step> steps;                        // in the reference's order
+};
+
+void plan_realign(const stitch_ctx& c, const std::vector<uint8_t>& query, const HAln& aln, std::vector<Job>& jobs, RealignPlan& plan) {
+    plan.original = aln;
+    const uint32_t slop = (uint32_t)c.opts.circular_slop;
+    const bool circ = c.opts.circular != 0;          // is_circular(): every aligner carries opts.circular (mod.rs:191,201)
+    bool at_start = aln.xstart <= slop && circ, at_end = aln.xlen <= aln.xend + slop && circ;      // :365-385
+    uint32_t cs = aln.start_contig_idx, ce = aln.end_contig_idx;
+    if (at_start && at_end && cs == ce) return;      // :389-395
+    if (!at_start && !at_end) return;
+    if (at_start && aln.yend == aln.ylen) at_start = false;                                          // :398-407
+    if (at_end && aln.ystart == 0) at_end = false;
+    if (!at_start && !at_end) return;
+    plan.needed = true;
+    std::vector<uint8_t> in(c.C, 0);
+    in[aln.start_contig_idx] = 1; in[aln.end_contig_idx] = 1;
+    for (const stitch_op& op : aln.ops) if (op.kind == OP_XJUMP) in[op.contig] = 1;
+    for (uint32_t a = 0; a < c.C; ++a) if (in[a]) plan.subset.push_back(a);
+    const uint32_t n = (uint32_t)query.size();
+    auto add = [&](uint32_t pivot_y, uint32_t contig) {
+        Job jb; jb.y.assign(query.begin() + pivot_y, query.end()); jb.y.insert(jb.y.end(), query.begin(), query.begin() + pivot_y);
+        jb.act = plan.subset; jb.mode = 2; jb.from = contig;
+        plan.steps.push_back({jobs.size(), contig, aln.ylen - pivot_y});
+        jobs.push_back(std::move(jb));
+    };
+    (void)n;
+    if (at_start) {                                   // :475-509
+        uint32_t yend = aln.ystart;
+        for (const stitch_op& op : aln.ops) { if (op.kind == OP_XJUMP && op.contig != cs) break; yend += op_len_y(op); }
+        add(aln.yend, cs); add(yend, cs);
+    }
+    if (at_end) {                                     // :512-550
+        uint32_t ystart = aln.ystart, ycur = aln.ystart, xidx = aln.start_contig_idx;
+        for (const stitch_op& op : aln.ops) {
+            if (op.kind == OP_XJUMP) { if (op.contig == ce && xidx != ce) ystart = ycur; xidx = op.contig; }
+            ycur += op_len_y(op);
+        }
+        add(aln.ystart, ce); add(ystart, ce);
+    }
+}
+
+HAln finish_realign(const stitch_ctx& c, const RealignPlan& plan, const std::vector<Job>& jobs) {
+    HAln best = plan.original;
+    for (const auto& st : plan.steps) {               // realign_and_split_at_y (mod.rs:412-431)
+        const Job& jb = jobs[st.job];
+        if (jb.status[0] == 1) continue;
+        HAln na = jb.chains[0];
+        if (na.score > best.score && na.start_contig_idx == st.contig && best.end_contig_idx == st.contig) {
+            if (!c.opts.keep_clipping) remove_clipping(c.opts, na);
+            best = split_at_y(na, 4, st.y_pivot);
+        }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+int stitch_align_batch(stitch_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                       const stitch_read_result** per_read, const stitch_chain** chains, const stitch_op** ops,
+                       uint64_t* cells_filled) {
+    if (!c || (!bases && n_reads) || !offsets) return fail(STITCH_EINVAL, "null argument");
+    auto t_host0 = std::chrono::steady_clock::now();
+    c->tm = stitch_timing{};
+    c->rr.clear(); c->chains.clear(); c->ops.clear(); c->per_read.assign(n_reads, {});
+    std::vector<uint32_t> all(c->C); for (uint32_t a = 0; a < c->C; ++a) all[a] = a;
+
+    // pass 1: one job per run of identical consecutive reads (FastxGroupingIterator, align/io.rs:118-146)
+    std::vector<Job> jobs; std::vector<uint32_t> job_of(n_reads);
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const uint8_t* s = bases + offsets[r]; const size_t n = (size_t)(offsets[r + 1] - offsets[r]);
+        if (n == 0) return fail(STITCH_EINVAL, "empty read");
+        if (r > 0) {
+            const size_t pn = (size_t)(offsets[r] - offsets[r - 1]);
+            if (pn == n && memcmp(bases + offsets[r - 1], s, n) == 0) { job_of[r] = job_of[r - 1]; continue; }
+        }
+        Job jb; jb.y.assign(s, s + n);
+        for (auto& b : jb.y) if (b >= 'a' && b <= 'z') b = (uint8_t)(b - 32);          // seq_upper_case (io.rs:64-66)
+        jb.act = all; jb.mode = c->opts.suboptimal ? 1 : 0;
+        job_of[r] = (uint32_t)jobs.size();
+        jobs.push_back(std::move(jb));
+    }
+    int rc = run_jobs(*c, jobs);
+    if (rc) return rc;
+
+    // host: chains of pass 1, realign planning
+    struct PerJob { std::vector<HAln> chains; std::vector<RealignPlan> plans; };
+    std::vector<PerJob> pj(jobs.size());
+    std::vector<Job> jobs2;
+    for (size_t k = 0; k < jobs.size(); ++k) {
+        std::vector<HAln> cand;
+        if (c->opts.suboptimal) cand = select_all(*c, jobs[k]);
+        else { if (jobs[k].status[0] != 0) return fail(STITCH_EINTERNAL, "primary traceback returned None"); cand.push_back(jobs[k].chains[0]); }
+        for (HAln& a : cand) { if (!c->opts.keep_clipping) remove_clipping(c->opts, a); }
+        pj[k].chains = cand;
+        pj[k].plans.resize(cand.size());
+        if (c->opts.circular) for (size_t q = 0; q < cand.size(); ++q) plan_realign(*c, jobs[k].y, cand[q], jobs2, pj[k].plans[q]);
+    }
+    if (!jobs2.empty()) { rc = run_jobs(*c, jobs2); if (rc) return rc; }
+    for (size_t k = 0; k < jobs.size(); ++k) {
+        for (size_t q = 0; q < pj[k].chains.size(); ++q)
+            if (pj[k].plans[q].needed) pj[k].chains[q] = finish_realign(*c, pj[k].plans[q], jobs2);
+        std::vector<HAln>& al = pj[k].chains;
+        if (c->opts.suboptimal && al.size() > 1) {                                        // mod.rs:318-329
+            std::stable_sort(al.begin(), al.end(), [](const HAln& a, const HAln& b) { return -a.score < -b.score; });
+            const float min_score = (float)al[0].score * c->opts.suboptimal_pct / 100.0f;
+            std::vector<HAln> kept; for (HAln& a : al) if ((float)a.score >= min_score) kept.push_back(a);
+            al.swap(kept);
+        }
+    }
+    // result arena, input order
+    c->rr.resize(n_reads);
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const std::vector<HAln>& al = pj[job_of[r]].chains;
+        stitch_read_result& R = c->rr[r]; memset(&R, 0, sizeof(R));
+        R.chains_begin = c->chains.size(); R.n_chains = (uint32_t)al.size();
+        for (const HAln& a : al) {
+            stitch_chain ch{}; ch.score = a.score; ch.xstart = a.xstart; ch.xend = a.xend; ch.ystart = a.ystart; ch.yend = a.yend; ch.xlen = a.xlen; ch.ylen = a.ylen;
+            ch.start_contig_idx = a.start_contig_idx; ch.end_contig_idx = a.end_contig_idx; ch.length = a.length;
+            ch.ops_begin = c->ops.size(); ch.ops_len = (uint32_t)a.ops.size();
+            c->ops.insert(c->ops.end(), a.ops.begin(), a.ops.end());
+            c->chains.push_back(ch);
+        }
+        c->per_read[r] = al;
+    }
+    if (per_read) *per_read = c->rr.data();
+    if (chains) *chains = c->chains.data();
+    if (ops) *ops = c->ops.data();
+    if (cells_filled) *cells_filled = c->tm.cells;
+    c->tm.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    return STITCH_OK;
+}
+
+long stitch_format_sam(stitch_ctx* c, uint32_t read_idx, const char* head, const uint8_t* bases, const uint8_t* quals,
+                       size_t n, char* buf, size_t cap) {
+    if (!c || !head || !bases) return fail(STITCH_EINVAL, "null argument");
+    if (read_idx >= c->per_read.size()) return fail(STITCH_EINVAL, "read_idx outside the last batch");
+    std::vector<std::string> recs; std::string err;
+    if (!format_sam_records(c->opts, c->targets, head, bases, quals, n, c->per_read[read_idx], c->rr[read_idx].has_prealign != 0,
+                            c->rr[read_idx].prealign_score, recs, err)) return fail(STITCH_EINVAL, err);
+    std::string all;
+    for (size_t k = 0; k < recs.size(); ++k) { if (k) all += "\n"; all += recs[k]; }
+    if (buf && all.size() < cap) memcpy(buf, all.c_str(), all.size() + 1);
+    return (long)all.size();
+}
+
+int stitch_last_timing(const stitch_ctx* c, stitch_timing* out) {
+    if (!c || !out) return fail(STITCH_EINVAL, "null argument");
+    *out = c->tm;
+    return STITCH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+// Last-column fix-ups and traceback walk over the compact traceback written by the fill kernel.
+//   fixup_contig  == SingleContigAligner::fill_last_column_and_end_clipping  (single_contig_aligner.rs:453-555)
+//   walk_from     == traceback_from                                           (align/traceback/mod.rs:219-373)
+//   pick_primary  == traceback                                                (align/traceback/mod.rs:129-150)
+// Both are serial per (read, contig) like the reference; on the GPU one lane runs each of them.
+#pragma once
+#include "dp_core.h"
+
+namespace stitch {
+
+struct ContigDesc {            // one per (contig, strand) aligner
+    uint32_t m;                // contig length
+    uint32_t roff;             // offset of row 1 in the per-read row arrays (rows 1..m are contiguous; compacted
+                               // over the read's active contigs)
+    uint32_t troff;            // offset of row 1 in the context-wide column-0 template arrays
+    uint32_t seqoff;           // offset of base 0 in the packed sequence array
+    uint32_t target;           // index of the FASTA record (contig_idx % T)
+    int32_t opp;               // aligner index of the same-name opposite strand, -1 if none (double_strand only)
+    uint32_t pad[2];
+};
+
+struct ChainHdr {              // == Alignment (align/alignment.rs:16-51)
+    int32_t score; uint32_t xstart, xend, ystart, yend, xlen, ylen;
+    uint32_t start_contig_idx, end_contig_idx, length, n_ops, status;   // status: 0 ok, 1 None, 2 overflow, 3 bad move
+};
+
+struct JobView {
+    DpParams P;
+    uint32_t n, C, nact, Rtot;
+    const uint32_t* act;       // active aligner ids in aligner order (the reference's `self.contigs` after sub-setting)
+    const int32_t* opp_act;    // [C] opposite-strand aligner id if both strands are active, else -1
+    const ContigDesc* cd;      // [C]
+    const uint8_t* xseq;       // contig bases (one byte per base)
+    const uint8_t* y;          // read bases, upper-cased
+    // per-read row state, [Rtot] each; after the fill they hold column n
+    int32_t* S; uint32_t* Slen; int32_t* D; uint32_t* Dlen; int32_t* Sn; uint32_t* SnLen; uint32_t* Ly;
+    uint8_t* tb;               // [n][Rtot] traceback bytes, column j at (j-1)*Rtot
+    uint32_t* Lx;              // [C][n+1]
+    uint32_t* jt_idx;          // [C][n+1] source contig of the column's best jump
+    uint32_t* jt_from;         // [C][n+1] source row
+    // column n: values the fix-ups need or change
+    int32_t* Ival; uint32_t* Ilen;                    // [Rtot] written by the fill at j == n
+    uint8_t* SmoveF; uint32_t* SidxF; uint32_t* SfromF; uint8_t* ImoveF;   // [Rtot] overrides, TB_NONE = untouched
+    // column 0 template (shared by all reads of a context)
+    const uint8_t* Smove0; const uint8_t* Imove0; const uint32_t* Slen0;   // indexed by ContigDesc::troff
+    // per-contig results of the fix-ups
+    int32_t* Sm; uint32_t* Lm;                        // [C] S[n%2][m] and cell(m,n).S.len
+};
+
+struct WalkArgs { ChainHdr* hdr; OpRec* ops; uint32_t ops_cap; int32_t mode; uint32_t from; uint32_t pad; };   // per job
+
+struct SCell { uint32_t tb, len, idx, from; };
+
+STITCH_HD uint32_t decode_move(const JobView& V, uint32_t c, uint32_t i, uint32_t j, uint32_t code) {
+    switch (code & 7u) {
+        case MV_XSUF: return TB_XCLIP_SUFFIX;
+        case MV_INS: return TB_INS;
+        case MV_DEL: return TB_DEL;
+        case MV_XPRE: return TB_XCLIP_PREFIX;
+        case MV_YPRE: return TB_YCLIP_PREFIX;
+        default: return V.xseq[V.cd[c].seqoff + i - 1] == V.y[j - 1] ? TB_MATCH : TB_SUBST;
+    }
+}
+// (idx, from) the reference stores next to the S move (set_s_all calls in single_contig_aligner.rs:357-399)
+STITCH_HD void decode_src(const JobView& V, uint32_t c, uint32_t i, uint32_t j, uint32_t code, uint32_t& idx, uint32_t& from) {
+    switch (code & 7u) {
+        case MV_XSUF: idx = 0; from = 0; break;              // Cell::default() idx/from survive set_s (:350)
+        case MV_INS: case MV_DIAG: idx = c; from = i - 1; break;
+        case MV_DEL: case MV_YPRE: idx = c; from = i; break;
+        case MV_XPRE: idx = c; from = 0; break;
+        case MV_CIRC: idx = c; from = V.cd[c].m; break;
+        default: idx = V.jt_idx[(size_t)c * (V.n + 1) + j]; from = V.jt_from[(size_t)c * (V.n + 1) + j]; break;   // MV_JUMP
+    }
+}
+STITCH_HD uint32_t tb_byte(const JobView& V, uint32_t c, uint32_t i, uint32_t j) {
+    return V.tb[(size_t)(j - 1) * V.Rtot + V.cd[c].roff + i - 1];
+}
+
+// S move of cell (i,j) of contig c as the reference's traceback matrix would hold it after the whole fill.
+STITCH_HD uint32_t s_move(const JobView& V, uint32_t c, uint32_t i, uint32_t j) {
+    if (j == 0) return i == 0 ? (uint32_t)TB_START : (uint32_t)V.Smove0[V.cd[c].troff + i - 1];
+    if (i == 0) return row0_at(V.P, j, V.n).Smove;
+    if (j == V.n) { uint8_t f = V.SmoveF[V.cd[c].roff + i - 1]; if (f != TB_NONE) return f; }
+    return decode_move(V, c, i, j, tb_byte(V, c, i, j));
+}
+STITCH_HD void s_src(const JobView& V, uint32_t c, uint32_t i, uint32_t j, uint32_t& idx, uint32_t& from) {
+    // only called for cells with i >= 1, j >= 1
+    uint32_t r = V.cd[c].roff + i - 1;
+    if (j == V.n && V.SmoveF[r] != TB_NONE) { idx = V.SidxF[r]; from = V.SfromF[r]; return; }
+    decode_src(V, c, i, j, tb_byte(V, c, i, j), idx, from);
+}
+STITCH_HD uint32_t i_move(const JobView& V, uint32_t c, uint32_t i, uint32_t j) {   // i >= 1
+    uint32_t r = V.cd[c].roff + i - 1;
+    if (j == 0) return V.Imove0[V.cd[c].troff + i - 1];
+    if (j == V.n) {
+        if (V.ImoveF[r] != TB_NONE) return V.ImoveF[r];
+        if (tb_byte(V, c, i, j) & TBB_IEXT) return TB_INS;
+        // copy taken while column n was filled, i.e. before any fix-up touched cell (i-1,n) (:324-325)
+        return i == 1 ? (uint32_t)row0_at(V.P, j, V.n).Smove : decode_move(V, c, i - 1, j, tb_byte(V, c, i - 1, j));
+    }
+    if (tb_byte(V, c, i, j) & TBB_IEXT) return TB_INS;
+    return s_move(V, c, i - 1, j);
+}
+STITCH_HD uint32_t d_move(const JobView& V, uint32_t c, uint32_t i, uint32_t j) {
+    if (j == 0) return TB_START;
+    if (i == 0) return row0_at(V.P, j, V.n).Dmove;
+    if (tb_byte(V, c, i, j) & TBB_DEXT) return TB_DEL;
+    return s_move(V, c, i, j - 1);                     // copy of cell(i,j-1).S.move (:336-337), final since j-1 < n
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fill_last_column_and_end_clipping for aligner c (single_contig_aligner.rs:453-555)
+// ------------------------------------------------------------------------------------------------------------
+STITCH_HD void fixup_contig(const JobView& V, uint32_t c) {
+    const DpParams& P = V.P;
+    const uint32_t m = V.cd[c].m, roff = V.cd[c].roff, n = V.n;
+    int32_t sn0; uint32_t ly0;
+    const Row0 r0 = row0_at(P, n, n, &sn0, &ly0);
+    int32_t S0 = r0.S;                                  // S[curr][0]
+    SCell c0; c0.tb = r0.Smove; c0.len = r0.Slen; c0.idx = c; c0.from = 0;   // cell(0,n).S
+    uint32_t* LxN = &V.Lx[(size_t)c * (n + 1) + n];
+
+    auto Sget = [&](uint32_t i) -> int32_t { return i == 0 ? S0 : V.S[roff + i - 1]; };
+    auto Sset = [&](uint32_t i, int32_t v) { if (i == 0) S0 = v; else V.S[roff + i - 1] = v; };
+    auto cell = [&](uint32_t i) -> SCell {
+        if (i == 0) return c0;
+        uint32_t r = roff + i - 1; SCell s; s.len = V.Slen[r];
+        if (V.SmoveF[r] != TB_NONE) { s.tb = V.SmoveF[r]; s.idx = V.SidxF[r]; s.from = V.SfromF[r]; }
+        else { uint32_t code = tb_byte(V, c, i, n); s.tb = decode_move(V, c, i, n, code); decode_src(V, c, i, n, code, s.idx, s.from); }
+        return s;
+    };
+    auto cell_set = [&](uint32_t i, uint32_t tb, uint32_t len, uint32_t idx, uint32_t from) {
+        if (i == 0) { c0.tb = tb; c0.len = len; c0.idx = idx; c0.from = from; return; }
+        uint32_t r = roff + i - 1;
+        V.SmoveF[r] = (uint8_t)tb; V.Slen[r] = len; V.SidxF[r] = idx; V.SfromF[r] = from;
+    };
+
+    for (uint32_t i = 0; i <= m; ++i) {
+        // (a) jump over the remaining bases of x (:460-466)
+        if (Sget(i) + P.jump_same > Sget(m)) {
+            Sset(m, Sget(i) + P.jump_same);
+            SCell ps = cell(i);
+            cell_set(m, TB_XJUMP, ps.len, ps.idx, i);
+        }
+        // (b) y suffix clip (:469-491); the equal branch compares a cell's length with itself
+        int32_t sn = i == 0 ? sn0 : V.Sn[roff + i - 1];
+        if (sn > Sget(i)) {
+            Sset(i, sn);
+            uint32_t ly = i == 0 ? ly0 : V.Ly[roff + i - 1];
+            uint32_t len = i == 0 ? (n - ly == 0 ? 0u : row0_at(P, n - ly, n).Slen) : V.SnLen[roff + i - 1];
+            (void)ly;
+            cell_set(i, TB_YCLIP_SUFFIX, len, c, i);     // idx of this cell is never consumed
+        }
+        // (c) x suffix clip (:494-516)
+        {
+            int32_t v = Sget(i) + P.xclip_suffix;
+            bool do_x = false;
+            if (v > Sget(m)) do_x = true;
+            else if (v == Sget(m)) do_x = cell(i).len > cell(m).len;
+            if (do_x) {
+                Sset(m, v);
+                *LxN = m - i;
+                SCell ps = cell(i);
+                cell_set(m, TB_XCLIP_SUFFIX, ps.len, ps.idx, i);
+            }
+        }
+    }
+    for (uint32_t i = 1; i <= m; ++i) {                  // :521-554
+        uint32_t r = roff + i - 1;
+        int32_t i_score = Sget(i - 1) + P.gap_open + P.gap_extend;
+        if (i_score > V.Ival[r]) {
+            V.Ival[r] = i_score;
+            SCell sv = cell(i - 1);
+            V.ImoveF[r] = (uint8_t)sv.tb; V.Ilen[r] = sv.len + 1;
+        }
+        if (i_score > Sget(i)) {
+            Sset(i, i_score);
+            uint32_t prev_len = V.Ilen[r];
+            cell_set(i, TB_INS, prev_len, c, i - 1);
+            if (Sget(i) + P.xclip_suffix > Sget(m)) {
+                Sset(m, Sget(i) + P.xclip_suffix);
+                *LxN = m - i;
+                cell_set(m, TB_XCLIP_SUFFIX, prev_len, c, i);
+            }
+        }
+    }
+    V.Sm[c] = Sget(m);
+    V.Lm[c] = cell(m).len;
+}
+
+// traceback (align/traceback/mod.rs:129-150): best end contig among the active aligners, in aligner order
+STITCH_HD uint32_t pick_primary(const JobView& V) {
+    uint32_t best = V.act[0]; int32_t score = MIN_SCORE; uint32_t alen = 0;
+    for (uint32_t k = 0; k < V.nact; ++k) {
+        uint32_t c = V.act[k];
+        int32_t s = V.Sm[c]; uint32_t l = V.Lm[c];
+        if (s > score || (s == score && l > alen)) { best = c; score = s; alen = l; }
+    }
+    return best;
+}
+
+STITCH_HD bool is_active(const JobView& V, uint32_t c) {
+    for (uint32_t k = 0; k < V.nact; ++k) if (V.act[k] == c) return true;
+    return false;
+}
+
+// traceback_from (align/traceback/mod.rs:219-373).  Ops are written in reverse and flipped at the end.
+STITCH_HD void walk_from(const JobView& V, uint32_t contig_index, ChainHdr& H, OpRec* ops, uint32_t ops_cap) {
+    const uint32_t n = V.n;
+    H.status = 0; H.n_ops = 0;
+    if (contig_index >= V.C || !is_active(V, contig_index)) { H.status = 1; return; }
+    uint32_t j = n, nops = 0;
+    uint32_t xstart = 0, ystart = 0, yend = n;
+    uint32_t cur = contig_index;
+    uint32_t i = V.cd[cur].m, xend = V.cd[cur].m;
+    const uint32_t xlen = V.cd[cur].m;
+    const int32_t score = V.Sm[cur];
+    const uint32_t alignment_length = V.Lm[cur];
+    uint32_t first_kind = 0xFF;                          // kind of operations[0] (the first op pushed)
+    uint32_t last_layer = s_move(V, cur, i, j);
+    const uint64_t max_steps = 2ull * ((uint64_t)n + 2) * ((uint64_t)V.Rtot + 2) + 64;   // free gaps + free jumps can emit ~n*m ops
+    uint64_t steps = 0;
+    auto push = [&](uint8_t kind, uint32_t contig, uint32_t arg) {
+        if (nops < ops_cap) { OpRec o; o.kind = kind; o.pad = 0; o.contig = (uint16_t)contig; o.arg = arg; ops[nops] = o; }
+        else H.status = 2;
+        if (nops == 0) first_kind = kind;
+        ++nops;
+    };
+    for (;;) {
+        if (++steps > max_steps) { H.status = 3; break; }
+        if (!is_active(V, cur)) { H.status = 1; return; }
+        uint32_t next_layer;
+        if (last_layer == TB_START) break;
+        if (last_layer == TB_INS) {
+            push(OP_INS, 0, 0);
+            next_layer = i_move(V, cur, i, j);
+            i -= 1;
+        } else if (last_layer == TB_DEL) {
+            push(OP_DEL, 0, 0);
+            next_layer = d_move(V, cur, i, j);
+            j -= 1;
+        } else if (last_layer == TB_MATCH || last_layer == TB_SUBST) {
+            push(last_layer == TB_MATCH ? OP_MATCH : OP_SUBST, 0, 0);
+            uint32_t idx, from; s_src(V, cur, i, j, idx, from);
+            if (idx != cur || from != i - 1) {
+                push(OP_XJUMP, cur, i - 1);
+                cur = idx;
+                if (cur >= V.C || !is_active(V, cur)) { H.status = 1; return; }
+            }
+            i = from; j -= 1;
+            next_layer = s_move(V, cur, i, j);
+        } else if (last_layer == TB_XCLIP_PREFIX) {
+            next_layer = s_move(V, cur, 0, j);
+            if (next_layer == TB_START || next_layer == TB_YCLIP_PREFIX) { push(OP_XCLIP, 0, i); xstart = i; }
+            i = 0;
+        } else if (last_layer == TB_XCLIP_SUFFIX) {
+            uint32_t lx = V.Lx[(size_t)cur * (n + 1) + j];
+            if (nops == 0 || first_kind == OP_YCLIP) { push(OP_XCLIP, 0, lx); xend = i - lx; }
+            i -= lx;
+            next_layer = s_move(V, cur, i, j);
+        } else if (last_layer == TB_YCLIP_PREFIX) {
+            push(OP_YCLIP, 0, j);
+            ystart = j; j = 0;
+            next_layer = s_move(V, cur, i, 0);
+        } else if (last_layer == TB_YCLIP_SUFFIX) {
+            // only reachable in column n: row 0 keeps Ly[0] in closed form, other rows in the Ly array
+            uint32_t ly;
+            if (i == 0) { int32_t sn0; row0_at(V.P, n, n, &sn0, &ly); } else ly = V.Ly[V.cd[cur].roff + i - 1];
+            push(OP_YCLIP, 0, ly);
+            uint32_t from = i == 0 ? 0u : V.SfromF[V.cd[cur].roff + i - 1];
+            j -= ly;
+            if (from != i) { push(OP_XJUMP, cur, i); i = from; }
+            yend = j;
+            next_layer = s_move(V, cur, i, j);
+        } else if (last_layer == TB_XJUMP) {
+            uint32_t r = V.cd[cur].roff + i - 1;
+            uint32_t idx = V.SidxF[r], from = V.SfromF[r];
+            push(OP_XJUMP, cur, i);
+            cur = idx;
+            if (cur >= V.C || !is_active(V, cur)) { H.status = 1; return; }
+            i = from;
+            next_layer = s_move(V, cur, i, j);
+        } else { H.status = 3; break; }
+        last_layer = next_layer;
+    }
+    if (H.status == 2) { H.n_ops = nops; return; }
+    for (uint32_t a = 0, b = nops; a + 1 < b; ++a, --b) { OpRec t = ops[a]; ops[a] = ops[b - 1]; ops[b - 1] = t; }
+    bool all_special = true;
+    for (uint32_t k = 0; k < nops; ++k) { uint8_t kd = ops[k].kind; if (!(kd == OP_XCLIP || kd == OP_YCLIP || kd == OP_XJUMP)) { all_special = false; break; } }
+    if (all_special) { xstart = 0; xend = 0; ystart = 0; yend = 0; }
+    H.score = score; H.xstart = xstart; H.xend = xend; H.ystart = ystart; H.yend = yend; H.xlen = xlen; H.ylen = n;
+    H.start_contig_idx = cur; H.end_contig_idx = contig_index; H.length = alignment_length; H.n_ops = nops;
+}
+
+}  // namespace stitch
