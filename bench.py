@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Benchmark of the `stitch align` hot path on MI355X (BASELINE.json: reads/sec + DP Gcells/sec on 10 kb synthetic
+ONT reads vs a 50 x 5 kb construct DB; configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W [--reads-per-step R]
+
+A step = one pass of the hot path (stitch_align_batch: DP fill, per-column jump reduce, fix-ups, traceback, chain
+assembly) over one batch of R synthetic reads per GPU.  Reads are sharded by rank (weak scaling: R per GPU is
+fixed); the only collective on the data path is the one-time broadcast of the serialized reference index from
+rank 0 (RCCL), outside the timed region.  Rank 0 prints ONE JSON line.
+
+roofline: the dominant kernel is the DP fill (stitch::fill_kernel).  `achieved` = algorithmic bytes (1 byte of
+traceback per DP cell) / the kernel's launch time measured inside the library with HIP events on
+the stream it runs on (stitch_last_timing).  cpu_baseline: the oracle (C++ restatement of the reference, "port")
+timed on this host on a bounded sample of the same workload, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_LANE_OPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads-per-step", type=int, default=64, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=10000)
+    ap.add_argument("--contigs", type=int, default=50)
+    ap.add_argument("--contig-len", type=int, default=5000)
+    ap.add_argument("--cpu-reads", type=int, default=1, help="reads in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+
+    import stitch_amd
+    from stitch_amd import synth
+
+    # ---- reference index: built on rank 0, broadcast once over RCCL as a byte blob -----------------------------
+    dev = torch.device("cuda", local_rank)
+    if rank == 0:
+        db = synth.make_db(args.contigs, args.contig_len, 1001)
+        index = stitch_amd.Index.from_targets([stitch_amd.TargetSeq(n, s) for n, s in db])
+        blob = index.serialize()
+    if world > 1:
+        n_blob = torch.tensor([len(blob) if rank == 0 else 0], dtype=torch.int64, device=dev)
+        dist.broadcast(n_blob, src=0)
+        t_blob = torch.empty(int(n_blob.item()), dtype=torch.uint8, device=dev)
+        if rank == 0:
+            t_blob.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        dist.broadcast(t_blob, src=0)
+        blob = bytes(t_blob.cpu().numpy().tobytes())
+    index = stitch_amd.Index.deserialize(blob)
+    aligners = stitch_amd.Aligners(stitch_amd.Builder().build_options(), index, device=local_rank)
+
+    # ---- this rank's shard of the synthetic reads (seed 42 + config id 2; rank-specific stream) ----------------
+    if rank != 0:
+        db = synth.make_db(args.contigs, args.contig_len, 1001)
+    R = args.reads_per_step
+    total_steps = args.warmup + args.steps
+    reads = synth.make_reads(db, R * total_steps, args.read_len, 44 + 1000 * rank)
+    batches = []
+    for s in range(total_steps):
+        chunk = reads[s * R:(s + 1) * R]
+        offs = np.zeros(len(chunk) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(r) for r in chunk])
+        batches.append((np.frombuffer(b"".join(chunk), dtype=np.uint8), offs))
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        aligners.align_packed(*batches[s])
+    sync()
+    t0 = time.perf_counter()
+    fill_ms = walk_ms = 0.0
+    cells = 0
+    launches = 0
+    mapped = 0
+    for s in range(args.warmup, total_steps):
+        res = aligners.align_packed(*batches[s])
+        tm = aligners.timing()
+        fill_ms += tm["fill_ms"]; walk_ms += tm["walk_ms"]; cells += tm["cells"]; launches += tm["launches"]
+        mapped += sum(1 for ch, _ in res if ch and ch[0].score >= 100)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        agg = torch.tensor([float(cells), fill_ms, float(launches)], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        cells_all = float(agg[0].item())
+    else:
+        cells_all = float(cells)
+
+    if rank == 0:
+        n_reads_all = R * args.steps * world
+        value = n_reads_all / dt
+        # roofline of the dominant kernel (this rank's launches; every rank runs the same kernel on the same shape)
+        fill_s = fill_ms / 1e3
+        achieved = (cells * 1.0 / fill_s) / 1e9 if fill_s > 0 else 0.0           # GB/s at 1 algorithmic byte per cell
+        out = {
+            "metric": "reads_per_sec", "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"{args.read_len} bp chimeric ONT-like reads vs {args.contigs}x{args.contig_len} bp construct DB, "
+                                   "local mode, single strand (BASELINE configs[1])",
+                       "reads_per_step_per_gpu": R, "cells_per_read": args.read_len * args.contigs * args.contig_len,
+                       "scoring": "A=1 B=-4 O=-6 E=-2 J=-10", "sharding": "reads by rank, index broadcast once"},
+            "gcells_per_sec": cells_all / dt / 1e9,
+            "mapped_fraction": mapped / float(R * args.steps),
+            "roofline": {"bound": "hbm", "kernel": "stitch::fill_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_cell": 1.0, "cells_per_launch": cells / max(1, launches),
+                         "avg_launch_ms": fill_ms / max(1, launches), "walk_kernel_ms_per_step": walk_ms / args.steps,
+                         "fill_gcells_per_sec": cells / fill_s / 1e9 if fill_s > 0 else 0.0},
+        }
+        if world == 1 and args.cpu_reads > 0:
+            from oracle import oracle as orc
+            sample = reads[:args.cpu_reads]
+            secs, ccells, _ = orc.cpu_bench([(n, s) for n, s in db], sample, threads=args.cpu_threads)
+            out["cpu_baseline"] = {"value": len(sample) / secs, "unit": "reads/s", "cores": args.cpu_threads, "kind": "port",
+                                   "sample": f"first {len(sample)} read(s) of the same workload, {ccells} cells in {secs:.1f} s "
+                                             f"({ccells / secs / 1e9:.3f} Gcells/s); C++ restatement of fulcrumgenomics/stitch "
+                                             f"(16-byte traceback cells, {os.cpu_count()} host cores visible)"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,6 +20,7 @@
 #include <vector>
 #include <set>
 #include <optional>
+#include <stdexcept>
 
 namespace orc {
 
@@ -61,9 +62,13 @@ struct Traceback {
     size_t rows = 0, cols = 0;
     std::vector<Cell> matrix;
     void init(size_t m, size_t n);
-    void set(size_t i, size_t j, const Cell& v) { matrix[i * cols + j] = v; }
-    const Cell& get(size_t i, size_t j) const { return matrix[i * cols + j]; }
-    Cell& get_mut(size_t i, size_t j) { return matrix[i * cols + j]; }
+    // debug_assert!(i < self.rows); debug_assert!(j < self.cols) (:104-105, :111-112, :117-118): a release build of the
+    // reference would silently read another row's cell here (or panic past the Vec's end), e.g. when the TB_XJUMP
+    // quirk (:329-338) carries a row index into a shorter contig.  The oracle reports it instead of imitating it.
+    void check(size_t i, size_t j) const { if (i >= rows || j >= cols) throw std::out_of_range("traceback index out of range (reference: debug_assert)"); }
+    void set(size_t i, size_t j, const Cell& v) { check(i, j); matrix[i * cols + j] = v; }
+    const Cell& get(size_t i, size_t j) const { check(i, j); return matrix[i * cols + j]; }
+    Cell& get_mut(size_t i, size_t j) { check(i, j); return matrix[i * cols + j]; }
 };
 
 // align/scoring.rs:11-23 (match_fn == bio MatchParams: byte equality -> match / mismatch)

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void fixup_walk_kernel(const JobView* __restric
     const JobView& V = jobs[blockIdx.x];
     const WalkArgs A = args[blockIdx.x];
     const int lane = threadIdx.x;
-    for (uint32_t k = lane; k < V.nact; k += 64) fixup_contig(V, V.act[k]);
+    if (!A.skip_fixup) for (uint32_t k = lane; k < V.nact; k += 64) fixup_contig(V, V.act[k]);
     __syncthreads();
     if (A.mode == 1) {
         for (uint32_t k = lane; k < V.nact; k += 64) walk_from(V, V.act[k], A.hdr[k], A.ops + (size_t)k * A.ops_cap, A.ops_cap);

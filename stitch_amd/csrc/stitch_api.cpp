@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstddef>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -358,7 +359,7 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
             V.SidxF = (uint32_t*)(B + L.off_SidxF); V.SfromF = (uint32_t*)(B + L.off_SfromF); V.ImoveF = B + L.off_ImoveF;
             V.Smove0 = c.d_Smove0; V.Imove0 = c.d_Imove0; V.Slen0 = c.d_Slen0;
             V.Sm = (int32_t*)(B + L.off_Sm); V.Lm = (uint32_t*)(B + L.off_Lm);
-            WalkArgs& A = wargs[q]; A.hdr = (ChainHdr*)(B + L.off_hdr); A.ops = (OpRec*)(B + L.off_ops); A.ops_cap = L.ops_cap; A.mode = jb.mode; A.from = jb.from; A.pad = 0;
+            WalkArgs& A = wargs[q]; A.hdr = (ChainHdr*)(B + L.off_hdr); A.ops = (OpRec*)(B + L.off_ops); A.ops_cap = L.ops_cap; A.mode = jb.mode; A.from = jb.from; A.skip_fixup = 0;
             c.tm.cells += (uint64_t)L.n * [&] { uint64_t s = 0; for (uint32_t a : jb.act) s += c.al[a].m; return s; }();
         }
         // launch-level tables live after the jobs
@@ -393,16 +394,34 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
             HIP_TRY(hipMemcpy(hdrs.data(), B + L.off_hdr, sizeof(ChainHdr) * (size_t)L.slots, hipMemcpyDeviceToHost));
             jb.chains.assign(L.slots, HAln()); jb.status.assign(L.slots, 0);
             for (uint32_t s = 0; s < L.slots; ++s) {
-                const ChainHdr& H = hdrs[s];
+                ChainHdr H = hdrs[s];
+                const uint8_t* ops_src = B + L.off_ops + sizeof(OpRec) * (size_t)s * L.ops_cap;
+                uint8_t* big = nullptr;
+                if (H.status == 2) {
+                    // more operations than the default buffer holds (only with free gaps/jumps): walk this chain again
+                    // into a buffer of the size the first walk counted; the fix-ups must not run twice
+                    struct Retry { ChainHdr h; WalkArgs a; };
+                    const size_t ops_bytes = sizeof(OpRec) * (size_t)H.n_ops;
+                    HIP_TRY(hipMalloc((void**)&big, align_up(sizeof(Retry), 256) + ops_bytes));
+                    Retry rt{}; rt.a.hdr = (ChainHdr*)big; rt.a.ops = (OpRec*)(big + align_up(sizeof(Retry), 256)); rt.a.ops_cap = H.n_ops;
+                    rt.a.mode = 2; rt.a.from = H.end_contig_idx; rt.a.skip_fixup = 1;
+                    HIP_TRY(hipMemcpy(big, &rt, sizeof(Retry), hipMemcpyHostToDevice));
+                    launch_fixup_walk(d_views + q, (const WalkArgs*)(big + offsetof(Retry, a)), 1, c.stream);
+                    HIP_TRY(hipStreamSynchronize(c.stream));
+                    HIP_TRY(hipMemcpy(&H, big, sizeof(ChainHdr), hipMemcpyDeviceToHost));
+                    ops_src = big + align_up(sizeof(Retry), 256);
+                }
                 jb.status[s] = H.status;
-                if (H.status >= 2) return fail(STITCH_EINTERNAL, "traceback failed on the device (status " + std::to_string(H.status) + ")");
-                if (H.status == 1) continue;
+                if (H.status == 4) { if (big) (void)hipFree(big); return fail(STITCH_EINVAL, "end-of-read jump into a shorter contig: the reference indexes its traceback matrix out of range here (traceback/mod.rs:329-338); result undefined"); }
+                if (H.status >= 2) { if (big) (void)hipFree(big); return fail(STITCH_EINTERNAL, "traceback failed on the device (status " + std::to_string(H.status) + ")"); }
+                if (H.status == 1) { if (big) (void)hipFree(big); continue; }
                 HAln& a = jb.chains[s];
                 a.score = H.score; a.xstart = H.xstart; a.xend = H.xend; a.ystart = H.ystart; a.yend = H.yend; a.xlen = H.xlen; a.ylen = H.ylen;
                 a.start_contig_idx = H.start_contig_idx; a.end_contig_idx = H.end_contig_idx; a.length = H.length;
                 a.ops.resize(H.n_ops);
                 static_assert(sizeof(OpRec) == sizeof(stitch_op), "op layout");
-                if (H.n_ops) HIP_TRY(hipMemcpy(a.ops.data(), B + L.off_ops + sizeof(OpRec) * (size_t)s * L.ops_cap, sizeof(OpRec) * (size_t)H.n_ops, hipMemcpyDeviceToHost));
+                if (H.n_ops) HIP_TRY(hipMemcpy(a.ops.data(), ops_src, sizeof(OpRec) * (size_t)H.n_ops, hipMemcpyDeviceToHost));
+                if (big) (void)hipFree(big);
             }
         }
         c.tm.d2h_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d2h0).count();

@@ -21,7 +21,7 @@ struct ContigDesc {            // one per (contig, strand) aligner
 
 struct ChainHdr {              // == Alignment (align/alignment.rs:16-51)
     int32_t score; uint32_t xstart, xend, ystart, yend, xlen, ylen;
-    uint32_t start_contig_idx, end_contig_idx, length, n_ops, status;   // status: 0 ok, 1 None, 2 overflow, 3 bad move
+    uint32_t start_contig_idx, end_contig_idx, length, n_ops, status;   // status: 0 ok, 1 None, 2 overflow, 3 bad move / runaway, 4 reference-undefined XJUMP
 };
 
 struct JobView {
@@ -47,7 +47,7 @@ struct JobView {
     int32_t* Sm; uint32_t* Lm;                        // [C] S[n%2][m] and cell(m,n).S.len
 };
 
-struct WalkArgs { ChainHdr* hdr; OpRec* ops; uint32_t ops_cap; int32_t mode; uint32_t from; uint32_t pad; };   // per job
+struct WalkArgs { ChainHdr* hdr; OpRec* ops; uint32_t ops_cap; int32_t mode; uint32_t from; uint32_t skip_fixup; };   // per job
 
 struct SCell { uint32_t tb, len, idx, from; };
 
@@ -207,7 +207,7 @@ STITCH_HD bool is_active(const JobView& V, uint32_t c) {
 // traceback_from (align/traceback/mod.rs:219-373).  Ops are written in reverse and flipped at the end.
 STITCH_HD void walk_from(const JobView& V, uint32_t contig_index, ChainHdr& H, OpRec* ops, uint32_t ops_cap) {
     const uint32_t n = V.n;
-    H.status = 0; H.n_ops = 0;
+    H.status = 0; H.n_ops = 0; H.end_contig_idx = contig_index;
     if (contig_index >= V.C || !is_active(V, contig_index)) { H.status = 1; return; }
     uint32_t j = n, nops = 0;
     uint32_t xstart = 0, ystart = 0, yend = n;
@@ -279,6 +279,9 @@ STITCH_HD void walk_from(const JobView& V, uint32_t contig_index, ChainHdr& H, O
             cur = idx;
             if (cur >= V.C || !is_active(V, cur)) { H.status = 1; return; }
             i = from;
+            // the source row belongs to the contig the jump came FROM; the reference indexes the other contig's
+            // matrix with it (debug_assert in traceback/mod.rs:111-112) — undefined when that contig is shorter
+            if (i > V.cd[cur].m) { H.status = 4; return; }
             next_layer = s_move(V, cur, i, j);
         } else { H.status = 3; break; }
         last_layer = next_layer;

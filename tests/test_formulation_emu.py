@@ -132,14 +132,26 @@ def compare_case(p, contigs, y, rng):
     subset = None
     if C > 1 and rng.random() < 0.4:
         subset = sorted(rng.sample(range(C), rng.randint(1, C - 1)))
-    want = al.custom(y, subset)
+    try:
+        want = al.custom(y, subset)
+    except RuntimeError as e:          # the reference itself is undefined here (oracle: "traceback index out of range")
+        assert "out of range" in str(e)
+        want = None
     got = emu.job(y, subset, 0)[0]
-    assert got.key() == want.key(), f"primary\nwant {want}\ngot  {got}\nparams {p}\ncontigs {contigs}\ny {y} subset {subset}"
+    if want is not None:
+        assert got is not None and got.key() == want.key(), f"primary\nwant {want}\ngot  {got}\nparams {p}\ncontigs {contigs}\ny {y} subset {subset}"
+    else:
+        assert got is None
     act = subset if subset is not None else list(range(C))
     # traceback_from every active contig == the per-end-contig candidates of traceback_all
     cands = emu.job(y, subset, 1)
     for k, c in enumerate(act):
-        w = al.traceback_from(len(y), c)
+        try:
+            w = al.traceback_from(len(y), c)
+        except RuntimeError as e:
+            assert "out of range" in str(e)
+            assert cands[k] is None
+            continue
         g = cands[k]
         assert (g is None) == (w is None)
         if w is not None:
