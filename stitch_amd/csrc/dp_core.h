@@ -150,6 +150,11 @@ STITCH_HD void row_jump(const ColCtx& cx, uint32_t i, int32_t a, int32_t& J, uin
 }
 
 // `col0_len` = cell(i,0).S.len, only dereferenced when the y-prefix clip wins (:395).
+// LOCAL = true is the specialisation for AlignmentMode::Local with gap_open + gap_extend < 0: all four clip penalties
+// are 0 (aligners/mod.rs:125), so the x-prefix clip candidate is exactly 0 with length 0 (:304-308, row 0 is a
+// zero-length y-prefix clip), every S is >= 0, the diagonal always beats the MIN seed (:357) and the y-prefix clip
+// candidate go + ge*i < 0 (:391-393) can never win.
+template <bool LOCAL = false>
 STITCH_HD void row_phase_a(const DpParams& P, const ColCtx& cx, uint32_t i, uint8_t p, int32_t Sp_up, uint32_t Slp_up,
                            int32_t Sp, uint32_t Slp, int32_t Dp, uint32_t Dlp, const uint32_t* col0_len, RowA& r) {
     const int32_t a = (p == cx.q) ? P.match : P.mismatch;
@@ -163,29 +168,101 @@ STITCH_HD void row_phase_a(const DpParams& P, const ColCtx& cx, uint32_t i, uint
     // S without the insertion (:350-399)
     int32_t bs = MIN_SCORE; uint32_t mv = MV_XSUF; uint32_t ln = 0;
     r.dg = Sp_up + a; const uint32_t dl = Slp_up + 1;
-    if (r.dg >= bs) { bs = r.dg; mv = MV_DIAG; ln = dl; }
+    if (LOCAL || r.dg >= bs) { bs = r.dg; mv = MV_DIAG; ln = dl; }
     if (r.bd > bs) { bs = r.bd; mv = MV_DEL; ln = r.dlen; }
     r.bs2 = bs;
     int32_t J; uint32_t Jl, Jm; row_jump(cx, i, a, J, Jl, Jm);      // (:373-382)
     if (J > bs || (J == bs && bs == r.dg && Jl > dl)) { bs = J; mv = Jm; ln = Jl; }
-    if (cx.xclip_score > bs) { bs = cx.xclip_score; mv = MV_XPRE; ln = cx.row0_len; }
-    const int32_t yc = P.yclip_prefix + P.gap_open + P.gap_extend * (int32_t)i;      // (:391-393)
-    if (yc > bs) { bs = yc; mv = MV_YPRE; ln = col0_len[i - 1]; }
+    if (LOCAL) { if (0 > bs) { bs = 0; mv = MV_XPRE; ln = 0; } }
+    else {
+        if (cx.xclip_score > bs) { bs = cx.xclip_score; mv = MV_XPRE; ln = cx.row0_len; }
+        const int32_t yc = P.yclip_prefix + P.gap_open + P.gap_extend * (int32_t)i;      // (:391-393)
+        if (yc > bs) { bs = yc; mv = MV_YPRE; ln = col0_len[i - 1]; }
+    }
     r.T = bs; r.Tl = ln; r.Tm = mv;
 }
 
 // Phase C: merge the insertion (bi, il) into the selection at its place in the priority order (:368-371).
+template <bool LOCAL = false>
 STITCH_HD void row_phase_c(const DpParams& P, const ColCtx& cx, uint32_t i, const RowA& r, int32_t bi, uint32_t il,
                            const uint32_t* col0_len, int32_t& S, uint32_t& Sl, uint32_t& mv) {
     if (bi > r.bs2) {
         int32_t bs = bi; mv = MV_INS; uint32_t ln = il;
         int32_t J; uint32_t Jl, Jm; row_jump(cx, i, r.a, J, Jl, Jm);
         if (J > bs) { bs = J; mv = Jm; ln = Jl; }             // the == rule needs bs == diag, impossible once bi > bs2 >= dg
-        if (cx.xclip_score > bs) { bs = cx.xclip_score; mv = MV_XPRE; ln = cx.row0_len; }
-        const int32_t yc = P.yclip_prefix + P.gap_open + P.gap_extend * (int32_t)i;
-        if (yc > bs) { bs = yc; mv = MV_YPRE; ln = col0_len[i - 1]; }
+        if (LOCAL) { if (0 > bs) { bs = 0; mv = MV_XPRE; ln = 0; } }
+        else {
+            if (cx.xclip_score > bs) { bs = cx.xclip_score; mv = MV_XPRE; ln = cx.row0_len; }
+            const int32_t yc = P.yclip_prefix + P.gap_open + P.gap_extend * (int32_t)i;
+            if (yc > bs) { bs = yc; mv = MV_YPRE; ln = col0_len[i - 1]; }
+        }
         S = bs; Sl = ln;
     } else { S = r.T; Sl = r.Tl; mv = r.Tm; }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Local-mode selection by ordered keys (used by fill_local16.hip and its CPU emulation).
+//
+// In Local mode the reference's chain of `if candidate > best` tests (:355-399) is a maximum under a total
+// order: higher score first, then the earlier candidate in the reference's order.  Encoding each candidate as
+//   key = score * 8 + priority        priority: diagonal 5 > deletion 4 > insertion 3 > jump 2 > x-prefix clip 1
+// turns the chain into integer max operations.  The one exception — a jump that ties with the DIAGONAL wins if its
+// alignment is longer (:374-377) — is the jump getting priority 6 exactly when J == diag && J.len > diag.len:
+// if some other candidate is strictly better than the diagonal the jump cannot tie with the best anyway, and if
+// the deletion/insertion merely tie with the diagonal the reference keeps the diagonal (they need `>`), so
+// `best == diag` holds and the rule applies.  The priorities double as the traceback byte's move code.
+// ------------------------------------------------------------------------------------------------------------
+enum : uint32_t { MK_XSUF = 0, MK_XPRE = 1, MK_JUMP = 2, MK_INS = 3, MK_DEL = 4, MK_DIAG = 5, MK_JUMPL = 6 };
+constexpr int32_t KEY_SCORE_FLOOR = -(1 << 27);    // scores below this are clamped before the * 8 (only MIN-seeded chains)
+
+struct RowK { int32_t Tk; uint32_t Tl; int32_t bd; uint32_t dlen; uint32_t dext; int32_t dg; };
+
+// js/jl: the jump candidate's score without the match term and its length (for row 1 of a circular contig the
+// caller passes the better of the column's jump and the end-to-start jump, see local_row1_jump).
+STITCH_HD void row_phase_a_key(const DpParams& P, uint8_t p, uint8_t q, int32_t js, uint32_t jl, int32_t Sp_up, uint32_t Slp_up,
+                               int32_t Sp, uint32_t Slp, int32_t Dp, uint32_t Dlp, RowK& r) {
+    const int32_t a = (p == q) ? P.match : P.mismatch;
+    const int32_t de = Dp + P.gap_extend;
+    const int32_t dop = Sp + P.gap_open + P.gap_extend;
+    r.bd = de > dop ? de : dop;
+    r.dext = (de == r.bd);
+    r.dlen = (r.dext ? Dlp : Slp) + 1;
+    r.dg = Sp_up + a; const uint32_t dl = Slp_up + 1;
+    const int32_t J = js + a;
+    const int32_t dgk = r.dg * 8 + (int32_t)MK_DIAG, bdk = r.bd * 8 + (int32_t)MK_DEL;
+    const int32_t Jk = J * 8 + (int32_t)((J == r.dg && jl > dl) ? MK_JUMPL : MK_JUMP);
+    int32_t k = dgk > bdk ? dgk : bdk; k = k > Jk ? k : Jk; k = k > (int32_t)MK_XPRE ? k : (int32_t)MK_XPRE;
+    r.Tk = k;
+    r.Tl = k == dgk ? dl : k == bdk ? r.dlen : k == (int32_t)MK_XPRE ? 0u : jl;
+}
+// merges the insertion: returns the final key; S = key >> 3 (arithmetic), move = key & 7
+STITCH_HD int32_t row_phase_c_key(const RowK& r, int32_t bi, uint32_t il, uint32_t& Sl) {
+    const int32_t bic = bi > KEY_SCORE_FLOOR ? bi : KEY_SCORE_FLOOR;
+    const int32_t bik = bic * 8 + (int32_t)MK_INS;
+    const int32_t k = r.Tk > bik ? r.Tk : bik;
+    Sl = k == bik ? il : r.Tl;
+    return k;
+}
+// Row 1 of a circular contig may take the zero-cost jump from row m of the previous column instead of the column's
+// best jump (get_jump_score_and_len :258-289).  Both candidates get the same match term added, so the choice does
+// not depend on the bases and is made once per (contig, column).
+STITCH_HD bool local_row1_circ(const ColCtx& cx) {
+    if (!cx.circ_ok) return false;
+    if (cx.jump.score > cx.circ_score) return false;
+    if (cx.circ_score == cx.jump.score && cx.circ_len <= cx.jump.len) return false;
+    return true;
+}
+// translation of a key-format traceback byte to the generic move codes the walk understands
+STITCH_HD uint32_t key_code_to_generic(uint32_t code, bool row1_circ) {
+    const uint32_t bits = code & (TBB_IEXT | TBB_DEXT);
+    switch (code & 7u) {
+        case MK_XSUF: return MV_XSUF | bits;
+        case MK_XPRE: return MV_XPRE | bits;
+        case MK_INS: return MV_INS | bits;
+        case MK_DEL: return MV_DEL | bits;
+        case MK_DIAG: return MV_DIAG | bits;
+        default: return (row1_circ ? MV_CIRC : MV_JUMP) | bits;      // MK_JUMP, MK_JUMPL
+    }
 }
 
 // Phase B: the insertion chain as a prefix max.  Row i may open from row i-1 with o_i = S'(i-1)+go+ge, where S' is

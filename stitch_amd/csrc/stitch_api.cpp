@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstddef>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -29,7 +30,8 @@ struct FillShared {
 };
 void launch_fill(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillShared& sh, hipStream_t stream);
 void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, hipStream_t stream);
-constexpr uint32_t TILE_ROWS = 256;   // 64 lanes x R=4 rows; contig row blocks are padded to this
+constexpr uint32_t TILE_ROWS = 512;   // 64 lanes x 8 rows (Local-mode kernel; the generic one uses 256): contig row blocks are padded to this
+void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillShared& sh, hipStream_t stream);
 }  // namespace stitch
 
 using namespace stitch;
@@ -74,6 +76,7 @@ struct stitch_ctx {
     std::vector<stitch_read_result> rr; std::vector<stitch_chain> chains; std::vector<stitch_op> ops;
     std::vector<std::vector<HAln>> per_read;     // for stitch_format_sam
     stitch_timing tm{};
+    bool tm_fast = false;                        // last run_jobs used the Local-mode 16-bit kernel
     size_t mem_limit = 0;                        // optional cap on arena bytes (STITCH_ARENA_BYTES), for tests
 };
 
@@ -260,7 +263,7 @@ namespace {
 struct JobLayout {
     uint32_t n, nact, Rj, slots, ops_cap;
     size_t off_S, off_Slen, off_D, off_Dlen, off_Sn, off_SnLen, off_Ly, off_Ival, off_Ilen, off_SidxF, off_SfromF, off_SmoveF, off_ImoveF,
-        off_tb, off_Lx, off_jti, off_jtf, off_Sm, off_Lm, off_y, off_act, off_opp, off_cd, off_hdr, off_ops, bytes;
+        off_st16, off_tb, off_Lx, off_jti, off_jtf, off_Sm, off_Lm, off_y, off_act, off_opp, off_cd, off_hdr, off_ops, bytes;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -278,6 +281,7 @@ JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
     L.off_Sn = take(4ull * R); L.off_SnLen = take(4ull * R); L.off_Ly = take(4ull * R);
     L.off_Ival = take(4ull * R); L.off_Ilen = take(4ull * R); L.off_SidxF = take(4ull * R); L.off_SfromF = take(4ull * R);
     L.off_SmoveF = take(R); L.off_ImoveF = take(R);
+    L.off_st16 = take(8ull * R);
     L.off_tb = take((size_t)L.n * R);
     L.off_Lx = take(4ull * c.C * (L.n + 1)); L.off_jti = take(4ull * c.C * (L.n + 1)); L.off_jtf = take(4ull * c.C * (L.n + 1));
     L.off_Sm = take(4ull * c.C); L.off_Lm = take(4ull * c.C);
@@ -285,6 +289,16 @@ JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
     L.off_hdr = take(sizeof(ChainHdr) * (size_t)L.slots); L.off_ops = take(sizeof(OpRec) * (size_t)L.slots * L.ops_cap);
     L.bytes = o;
     return L;
+}
+
+// The Local-mode kernel keeps scores and alignment lengths in 16 bits (fill_local16.hip).
+bool local16_ok(const stitch_ctx& c, const Job& jb) {
+    const stitch_opts& o = c.opts;
+    if (getenv("STITCH_FORCE_GENERIC")) return false;
+    const long long n = (long long)jb.y.size();
+    const int32_t lo = std::min({o.mismatch_score, o.gap_open + o.gap_extend, o.jump_same, o.jump_opposite, o.jump_inter, o.match_score});
+    return o.mode == 0 && o.gap_open + o.gap_extend < 0 && (long long)std::max(o.match_score, 0) * n <= 32767 &&
+           n + (long long)c.max_m + 2 <= 65535 && lo >= -16000 && o.match_score <= 16000;
 }
 
 int pick_waves(uint32_t nact) {                    // fewest rounds of contigs per column, then fewest waves
@@ -313,6 +327,9 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
         c.arena_bytes = arena_need;
     }
     FillShared sh{c.d_S0, c.d_Slen0, c.d_Sn0, c.d_SnSet0, c.d_Smove0, c.d_lx0, c.d_base0};
+    bool fast = true;
+    for (const Job& jb : jobs) if (!local16_ok(c, jb)) { fast = false; break; }
+    c.tm_fast = fast;
 
     size_t k0 = 0;
     while (k0 < jobs.size()) {
@@ -349,10 +366,12 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
             HIP_TRY(hipMemcpyAsync(B + L.off_cd, cd.data(), sizeof(ContigDesc) * (size_t)c.C, hipMemcpyHostToDevice, c.stream));
             HIP_TRY(hipStreamSynchronize(c.stream));            // cd/opp are stack vectors
             JobView& V = views[q];
+            V.tb_keyfmt = fast ? 1u : 0u;
             V.P = c.P; V.n = L.n; V.C = c.C; V.nact = L.nact; V.Rtot = L.Rj;
             V.act = (const uint32_t*)(B + L.off_act); V.opp_act = (const int32_t*)(B + L.off_opp); V.cd = (const ContigDesc*)(B + L.off_cd);
             V.xseq = c.d_xseq; V.y = B + L.off_y;
             V.S = (int32_t*)(B + L.off_S); V.Slen = (uint32_t*)(B + L.off_Slen); V.D = (int32_t*)(B + L.off_D); V.Dlen = (uint32_t*)(B + L.off_Dlen);
+            V.st16 = (uint32_t*)(B + L.off_st16);
             V.Sn = (int32_t*)(B + L.off_Sn); V.SnLen = (uint32_t*)(B + L.off_SnLen); V.Ly = (uint32_t*)(B + L.off_Ly);
             V.tb = B + L.off_tb; V.Lx = (uint32_t*)(B + L.off_Lx); V.jt_idx = (uint32_t*)(B + L.off_jti); V.jt_from = (uint32_t*)(B + L.off_jtf);
             V.Ival = (int32_t*)(B + L.off_Ival); V.Ilen = (uint32_t*)(B + L.off_Ilen); V.SmoveF = B + L.off_SmoveF;
@@ -374,9 +393,11 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
 
         // Kernel 1 and 2, timed with events on the stream they run on
         HIP_TRY(hipEventRecord(c.ev[0], c.stream));
-        launch_fill(d_views, nj, waves, sh, c.stream);
+        if (fast) launch_fill_local16(d_views, nj, waves, sh, c.stream);
+        else launch_fill(d_views, nj, waves, sh, c.stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev[1], c.stream));
+        if (getenv("STITCH_DEBUG")) { HIP_TRY(hipStreamSynchronize(c.stream)); fprintf(stderr, "[stitch] fill done (%u jobs, fast=%d)\n", nj, (int)fast); }
         launch_fixup_walk(d_views, d_wargs, nj, c.stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev[2], c.stream));

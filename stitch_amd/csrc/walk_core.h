@@ -27,6 +27,7 @@ struct ChainHdr {              // == Alignment (align/alignment.rs:16-51)
 struct JobView {
     DpParams P;
     uint32_t n, C, nact, Rtot;
+    uint32_t tb_keyfmt;        // 1: traceback bytes are in the Local-mode kernel's key format
     const uint32_t* act;       // active aligner ids in aligner order (the reference's `self.contigs` after sub-setting)
     const int32_t* opp_act;    // [C] opposite-strand aligner id if both strands are active, else -1
     const ContigDesc* cd;      // [C]
@@ -34,6 +35,7 @@ struct JobView {
     const uint8_t* y;          // read bases, upper-cased
     // per-read row state, [Rtot] each; after the fill they hold column n
     int32_t* S; uint32_t* Slen; int32_t* D; uint32_t* Dlen; int32_t* Sn; uint32_t* SnLen; uint32_t* Ly;
+    uint32_t* st16;            // [2*Rtot] packed row state of the Local-mode kernel: {S | S.len<<16, D | D.len<<16}
     uint8_t* tb;               // [n][Rtot] traceback bytes, column j at (j-1)*Rtot
     uint32_t* Lx;              // [C][n+1]
     uint32_t* jt_idx;          // [C][n+1] source contig of the column's best jump
@@ -48,6 +50,8 @@ struct JobView {
 };
 
 struct WalkArgs { ChainHdr* hdr; OpRec* ops; uint32_t ops_cap; int32_t mode; uint32_t from; uint32_t skip_fixup; };   // per job
+
+constexpr uint32_t JT_CIRC_BIT = 0x80000000u;
 
 struct SCell { uint32_t tb, len, idx, from; };
 
@@ -69,11 +73,15 @@ STITCH_HD void decode_src(const JobView& V, uint32_t c, uint32_t i, uint32_t j, 
         case MV_DEL: case MV_YPRE: idx = c; from = i; break;
         case MV_XPRE: idx = c; from = 0; break;
         case MV_CIRC: idx = c; from = V.cd[c].m; break;
-        default: idx = V.jt_idx[(size_t)c * (V.n + 1) + j]; from = V.jt_from[(size_t)c * (V.n + 1) + j]; break;   // MV_JUMP
+        default: idx = V.jt_idx[(size_t)c * (V.n + 1) + j] & ~JT_CIRC_BIT; from = V.jt_from[(size_t)c * (V.n + 1) + j]; break;   // MV_JUMP
     }
 }
+// Traceback byte of cell (i,j) in the generic move codes.  The Local-mode kernel writes key-format bytes (dp_core.h)
+// and flags "row 1 took the circular jump" in bit 31 of the column's jump-table entry.
 STITCH_HD uint32_t tb_byte(const JobView& V, uint32_t c, uint32_t i, uint32_t j) {
-    return V.tb[(size_t)(j - 1) * V.Rtot + V.cd[c].roff + i - 1];
+    const uint32_t raw = V.tb[(size_t)(j - 1) * V.Rtot + V.cd[c].roff + i - 1];
+    if (!V.tb_keyfmt) return raw;
+    return key_code_to_generic(raw, i == 1 && (V.jt_idx[(size_t)c * (V.n + 1) + j] & JT_CIRC_BIT) != 0);
 }
 
 // S move of cell (i,j) of contig c as the reference's traceback matrix would hold it after the whole fill.
@@ -218,7 +226,8 @@ STITCH_HD void walk_from(const JobView& V, uint32_t contig_index, ChainHdr& H, O
     const uint32_t alignment_length = V.Lm[cur];
     uint32_t first_kind = 0xFF;                          // kind of operations[0] (the first op pushed)
     uint32_t last_layer = s_move(V, cur, i, j);
-    const uint64_t max_steps = 2ull * ((uint64_t)n + 2) * ((uint64_t)V.Rtot + 2) + 64;   // free gaps + free jumps can emit ~n*m ops
+    uint64_t max_steps = 2ull * ((uint64_t)n + 2) * ((uint64_t)V.Rtot + 2) + 64;   // free gaps + free jumps can emit ~n*m ops
+    if (max_steps > 50000000ull) max_steps = 50000000ull;                           // a runaway walk must end in seconds, not hours
     uint64_t steps = 0;
     auto push = [&](uint8_t kind, uint32_t contig, uint32_t arg) {
         if (nops < ops_cap) { OpRec o; o.kind = kind; o.pad = 0; o.contig = (uint16_t)contig; o.arg = arg; ops[nops] = o; }

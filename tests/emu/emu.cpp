@@ -18,6 +18,7 @@ using namespace stitch;
 namespace {
 constexpr int R = 4;
 constexpr uint32_t TILE = 64 * R;
+constexpr uint32_t PAD = 512;      // row blocks are padded to the larger (Local-mode) tile
 
 struct EmuCtx {
     DpParams P; uint32_t C = 0;
@@ -38,7 +39,7 @@ void emu_fill(const EmuCtx& X, EmuJob& J) {
     std::vector<uint8_t> rowm_mv(X.C); std::vector<int32_t> rowm_S(X.C); std::vector<uint32_t> rowm_len(X.C);
     for (uint32_t k = 0; k < nact; ++k) {
         uint32_t c = V.act[k]; const ContigDesc& cd = V.cd[c];
-        uint32_t mpad = (cd.m + TILE - 1) / TILE * TILE;
+        uint32_t mpad = (cd.m + PAD - 1) / PAD * PAD;
         for (uint32_t i = 0; i < mpad; ++i) {
             uint32_t r = cd.roff + i, tr = cd.troff + i;
             V.S[r] = X.S0[tr]; V.Slen[r] = X.Slen0[tr]; V.D[r] = MIN_SCORE; V.Dlen[r] = 0;
@@ -156,6 +157,109 @@ void emu_fill(const EmuCtx& X, EmuJob& J) {
     }
 }
 
+// ---- emulation of fill_local16.hip: key-based selection, 16-bit packed state, 8 rows per lane, filtered Sn ----------
+inline uint32_t pk16(int32_t v, uint32_t len) { return ((uint32_t)v << 16) | (len & 0xFFFFu); }
+void emu_fill_local(const EmuCtx& X, EmuJob& J) {
+    constexpr int R8 = 8; constexpr uint32_t T8 = 64 * R8;
+    JobView& V = J.V; const DpParams P = V.P; const uint32_t n = V.n, nact = V.nact, Rtot = V.Rtot;
+    std::vector<uint32_t> st(2 * (size_t)Rtot);
+    std::vector<JumpBase> base(X.C); std::vector<int32_t> vrun(X.C), rowm_S(X.C); std::vector<uint8_t> rowm_mv(X.C); std::vector<uint32_t> rowm_len(X.C);
+    for (uint32_t k = 0; k < nact; ++k) {
+        uint32_t c = V.act[k]; const ContigDesc& cd = V.cd[c];
+        uint32_t mpad = (cd.m + PAD - 1) / PAD * PAD;
+        for (uint32_t i = 0; i < mpad; ++i) {
+            uint32_t r = cd.roff + i, tr = cd.troff + i;
+            st[2 * r] = pk16(X.S0[tr], X.Slen0[tr]); st[2 * r + 1] = pk16(-32768, 0);
+            V.Sn[r] = X.Sn0[tr]; V.SnLen[r] = X.Slen0[tr]; V.Ly[r] = X.SnSet0[tr] ? n : 0u; V.SmoveF[r] = TB_NONE; V.ImoveF[r] = TB_NONE;
+        }
+        uint32_t trm = cd.troff + cd.m - 1;
+        base[c] = X.base0[c]; vrun[c] = X.base0[c].score; rowm_mv[c] = X.Smove0[trm]; rowm_S[c] = X.S0[trm]; rowm_len[c] = X.Slen0[trm];
+        V.Lx[(size_t)c * (n + 1)] = X.lx0[c];
+    }
+    for (uint32_t j = 1; j <= n; ++j) {
+        std::vector<JumpInfo> sj(X.C); std::vector<uint8_t> scirc(X.C);
+        for (uint32_t k = 0; k < nact; ++k) {
+            uint32_t c = V.act[k];
+            JumpInfo ji = select_jump(P, base.data(), V.act, nact, c, V.opp_act[c]);
+            ColCtx cx{}; cx.jump = ji; cx.circ_ok = (P.circular && rowm_mv[c] != TB_XCLIP_SUFFIX) ? 1 : 0; cx.circ_score = rowm_S[c]; cx.circ_len = rowm_len[c] + 1;
+            scirc[c] = local_row1_circ(cx) ? 1 : 0; sj[c] = ji;
+            V.jt_idx[(size_t)c * (n + 1) + j] = ji.idx | (scirc[c] ? JT_CIRC_BIT : 0u); V.jt_from[(size_t)c * (n + 1) + j] = ji.from;
+        }
+        const uint8_t q = V.y[j - 1];
+        uint8_t* tbcol = V.tb + (size_t)(j - 1) * Rtot;
+        for (uint32_t k = 0; k < nact; ++k) {
+            const uint32_t c = V.act[k]; const ContigDesc cd = V.cd[c]; const uint32_t m = cd.m, roff = cd.roff;
+            const uint8_t* xs = V.xseq + cd.seqoff;
+            const int32_t js = sj[c].score; const uint32_t jl = sj[c].len;
+            const int32_t js1 = scirc[c] ? rowm_S[c] : js; const uint32_t jl1 = scirc[c] ? rowm_len[c] + 1 : jl;
+            const int32_t vr = vrun[c];
+            int32_t upS = 0, upT = 0; uint32_t upSl = 0, upTl = 0;
+            ScanEl carry = scan_seed();
+            XsRec xb_; xb_.v = MIN_SCORE; xb_.len = 0; xb_.row = 0; CmRec cb_; cb_.v = 0; cb_.row = 0; cb_.len = 0;
+            int32_t ownK = 0, ownDg = 0; uint32_t ownSl = 0, ownBits = 0, ownD = 0;
+            const uint32_t ntiles = (m + T8 - 1) / T8;
+            for (uint32_t t = 0; t < ntiles; ++t) {
+                static int32_t Sp[64][R8], Dp[64][R8]; static uint32_t Slp[64][R8], Dlp[64][R8]; static RowK ra[64][R8]; static ScanEl el[64][R8], agg[64], inc[64], run[64];
+                for (int l = 0; l < 64; ++l) for (int u = 0; u < R8; ++u) {
+                    uint32_t r = roff + t * T8 + l * R8 + u;
+                    Sp[l][u] = (int32_t)(st[2 * r] >> 16); Slp[l][u] = st[2 * r] & 0xFFFFu; Dp[l][u] = (int32_t)(int16_t)(st[2 * r + 1] >> 16); Dlp[l][u] = st[2 * r + 1] & 0xFFFFu;
+                }
+                for (int l = 0; l < 64; ++l) for (int u = 0; u < R8; ++u) {
+                    uint32_t i = t * T8 + l * R8 + u + 1;
+                    int32_t nS = u ? Sp[l][u - 1] : (l ? Sp[l - 1][R8 - 1] : upS); uint32_t nSl = u ? Slp[l][u - 1] : (l ? Slp[l - 1][R8 - 1] : upSl);
+                    row_phase_a_key(P, xs[i - 1], q, i == 1 ? js1 : js, i == 1 ? jl1 : jl, nS, nSl, Sp[l][u], Slp[l][u], Dp[l][u], Dlp[l][u], ra[l][u]);
+                }
+                upS = Sp[63][R8 - 1]; upSl = Slp[63][R8 - 1];
+                for (int l = 0; l < 64; ++l) {
+                    for (int u = 0; u < R8; ++u) {
+                        uint32_t i = t * T8 + l * R8 + u + 1;
+                        int32_t nT = u ? (ra[l][u - 1].Tk >> 3) : (l ? (ra[l - 1][R8 - 1].Tk >> 3) : upT);
+                        uint32_t nTl = u ? ra[l][u - 1].Tl : (l ? ra[l - 1][R8 - 1].Tl : upTl);
+                        el[l][u] = scan_make(P, i, nT, nTl);
+                        if (i > m) el[l][u].key = KEY_NEG_INF;
+                    }
+                    agg[l] = el[l][0]; for (int u = 1; u < R8; ++u) agg[l] = scan_combine(agg[l], el[l][u]);
+                }
+                upT = ra[63][R8 - 1].Tk >> 3; upTl = ra[63][R8 - 1].Tl;
+                inc[0] = agg[0]; for (int l = 1; l < 64; ++l) inc[l] = scan_combine(inc[l - 1], agg[l]);
+                for (int l = 0; l < 64; ++l) run[l] = l == 0 ? carry : scan_combine(carry, inc[l - 1]);
+                carry = scan_combine(carry, inc[63]);
+                for (int l = 0; l < 64; ++l) for (int u = 0; u < R8; ++u) {
+                    uint32_t i = t * T8 + l * R8 + u + 1, r = roff + i - 1; bool valid = i <= m;
+                    uint32_t ext = run[l].key >= el[l][u].key ? 1u : 0u; if (!ext) run[l] = el[l][u];
+                    int32_t bi = run[l].key + P.gap_extend * (int32_t)i; uint32_t il = (uint32_t)(run[l].q + (int32_t)i);
+                    uint32_t Slo; int32_t fk = row_phase_c_key(ra[l][u], bi, il, Slo); int32_t So = fk >> 3;
+                    uint32_t code = ((uint32_t)fk & 7u) | (ext ? TBB_IEXT : 0u) | (ra[l][u].dext ? TBB_DEXT : 0u);
+                    if (!valid) { st[2 * r] = 0; st[2 * r + 1] = pk16(-32768, 0); continue; }
+                    st[2 * r + 1] = pk16(ra[l][u].bd, ra[l][u].dlen);
+                    if (j == n) { V.Ival[r] = bi; V.Ilen[r] = il; }
+                    if (i < m) {
+                        st[2 * r] = pk16(So, Slo); tbcol[r] = (uint8_t)code;
+                        if (j == n) { V.S[r] = So; V.Slen[r] = Slo; }
+                        XsRec xc; xc.v = So; xc.len = Slo; xc.row = i; if (xs_better(xc, xb_)) xb_ = xc;
+                        CmRec cc; cc.v = So; cc.row = i; cc.len = Slo; if (cm_better(cc, cb_)) cb_ = cc;
+                        if (So >= vr && Slo > 0u && So >= V.Sn[r]) { V.Sn[r] = So; V.Ly[r] = n - j; V.SnLen[r] = Slo; }
+                    } else { ownK = fk; ownSl = Slo; ownBits = code & (TBB_IEXT | TBB_DEXT); ownDg = ra[l][u].dg; ownD = st[2 * r + 1]; }
+                }
+            }
+            const uint32_t rm = roff + m - 1;
+            int32_t ownS = ownK >> 3; uint32_t ownMv = (uint32_t)ownK & 7u;
+            int32_t Sm; uint32_t Slm, mvm, lx = xb_.row == 0 ? 0u : m - xb_.row; bool do_x_m = false;
+            if (rowm_run_wins(xb_.v, ownS, ownDg)) { Sm = xb_.v; Slm = xb_.len; mvm = MK_XSUF; }
+            else { Sm = ownS; Slm = ownSl; mvm = ownMv; if (ownSl > xb_.len) { do_x_m = true; lx = 0; } }
+            st[2 * rm] = pk16(Sm, Slm); st[2 * rm + 1] = ownD; tbcol[rm] = (uint8_t)(mvm | ownBits);
+            if (j == n) { V.S[rm] = Sm; V.Slen[rm] = Slm; }
+            uint32_t rl = (j == n) ? (do_x_m ? ownSl : xb_.len) : 0u;
+            if (Sm >= vr) { int32_t sn = V.Sn[rm]; if (Sm > sn || (Sm == sn && Slm > rl)) { V.Sn[rm] = Sm; V.Ly[rm] = n - j; V.SnLen[rm] = Slm; } }
+            V.Lx[(size_t)c * (n + 1) + j] = lx;
+            CmRec cc; cc.v = Sm; cc.row = m; cc.len = Slm; if (cm_better(cc, cb_)) cb_ = cc;
+            JumpBase b; b.score = cb_.v; b.len = cb_.len + 1; b.from = cb_.row; base[c] = b;
+            if (cb_.v > vr) vrun[c] = cb_.v;
+            rowm_mv[c] = (uint8_t)(mvm == MK_XSUF ? TB_XCLIP_SUFFIX : TB_MATCH); rowm_S[c] = Sm; rowm_len[c] = Slm;
+        }
+    }
+}
+
 size_t put_chain(const ChainHdr& H, const OpRec* ops, int64_t* out, size_t cap) {
     size_t need = 12 + 3 * (size_t)H.n_ops;
     if (need > cap) return need;
@@ -185,8 +289,8 @@ void* emu_ctx_new(const int32_t* params, uint32_t C, const char* const* names, c
     for (uint32_t a = 0; a < C; ++a) {
         ContigDesc d{}; d.m = lens[a]; d.troff = troff; d.roff = 0; d.seqoff = (uint32_t)X->xseq.size(); d.target = a; d.opp = -1;
         X->xseq.insert(X->xseq.end(), seqs[a], seqs[a] + lens[a]);
-        while (X->xseq.size() % TILE) X->xseq.push_back(0);
-        troff += (d.m + TILE - 1) / TILE * TILE;
+        while (X->xseq.size() % PAD) X->xseq.push_back(0);
+        troff += (d.m + PAD - 1) / PAD * PAD;
         X->cd.push_back(d); X->names.emplace_back(names[a]); X->fwd.push_back((uint8_t)is_fwd[a]);
     }
     for (uint32_t a = 0; a < C; ++a) {
@@ -215,13 +319,13 @@ void emu_ctx_free(void* h) { delete (EmuCtx*)h; }
 // Runs one DP job and writes chains in the oracle's wire format, concatenated; returns the number of chains or <0.
 // mode 0: traceback, 1: one chain per active contig (status None => n_ops = -1 marker), 2: traceback_from(from)
 long emu_job(void* h, const uint8_t* y, uint32_t n, const uint32_t* act, uint32_t nact, int mode, uint32_t from, int64_t* out, size_t cap,
-             size_t* used) {
+             size_t* used, int local16) {
     const EmuCtx& X = *(EmuCtx*)h;
     EmuJob J; J.y.assign(y, y + n); J.act.assign(act, act + nact); J.cd = X.cd; J.opp.assign(X.C, -1);
     std::vector<uint8_t> isact(X.C, 0); for (uint32_t a : J.act) isact[a] = 1;
     uint32_t roff = 0;
     for (uint32_t a = 0; a < X.C; ++a) {
-        if (isact[a]) { J.cd[a].roff = roff; roff += (J.cd[a].m + TILE - 1) / TILE * TILE; }
+        if (isact[a]) { J.cd[a].roff = roff; roff += (J.cd[a].m + PAD - 1) / PAD * PAD; }
         if (isact[a] && X.cd[a].opp >= 0 && isact[X.cd[a].opp]) J.opp[a] = X.cd[a].opp;
     }
     const uint32_t Rj = roff;
@@ -236,7 +340,8 @@ long emu_job(void* h, const uint8_t* y, uint32_t n, const uint32_t* act, uint32_
     V.jt_from = J.jtf.data(); V.Ival = J.Ival.data(); V.Ilen = J.Ilen.data(); V.SmoveF = J.SmoveF.data(); V.SidxF = J.SidxF.data();
     V.SfromF = J.SfromF.data(); V.ImoveF = J.ImoveF.data(); V.Smove0 = X.Smove0.data(); V.Imove0 = X.Imove0.data(); V.Slen0 = X.Slen0.data();
     V.Sm = J.Sm.data(); V.Lm = J.Lm.data();
-    emu_fill(X, J);
+    V.tb_keyfmt = local16 ? 1u : 0u;
+    if (local16) emu_fill_local(X, J); else emu_fill(X, J);
     for (uint32_t k = 0; k < nact; ++k) fixup_contig(V, act[k]);
     uint32_t max_m = 0; for (auto& d : X.cd) max_m = d.m > max_m ? d.m : max_m;
     const uint32_t ops_cap = (n + 1) * (max_m + 2) + 64;   // degenerate scorings (free gaps and jumps) can emit ~n*m ops

@@ -171,3 +171,36 @@ def test_random_multi_tile(seed):
     rng = random.Random(10_000 + seed)
     p, contigs, y = random_case(rng, big=True)
     compare_case(p, contigs, y, rng)
+
+
+def local16_eligible(p):
+    """mirror of local16_ok() in stitch_amd/csrc/stitch_api.cpp"""
+    return p[7:11] == [0, 0, 0, 0] and p[2] + p[3] < 0
+
+
+def compare_local(p, contigs, y, rng):
+    emu = Emu(p, contigs)
+    al = oracle_multi(p, contigs)
+    C = len(contigs)
+    subset = None
+    if C > 1 and rng.random() < 0.4:
+        subset = sorted(rng.sample(range(C), rng.randint(1, C - 1)))
+    want = al.custom(y, subset)
+    got = emu.job(y, subset, 0, local16=True)[0]
+    assert got.key() == want.key(), f"primary\nwant {want}\ngot  {got}\nparams {p}\ncontigs {contigs}\ny {y} subset {subset}"
+    act = subset if subset is not None else list(range(C))
+    cands = emu.job(y, subset, 1, local16=True)
+    for k, c in enumerate(act):
+        w = al.traceback_from(len(y), c)
+        assert cands[k].key() == w.key(), f"from {c}\nwant {w}\ngot  {cands[k]}\nparams {p}\ncontigs {contigs}\ny {y} subset {subset}"
+
+
+@pytest.mark.parametrize("seed", range(600))
+def test_random_local16(seed):
+    """the Local-mode kernel's formulation: ordered-key selection, 16-bit state, filtered y-suffix trackers"""
+    rng = random.Random(50_000 + seed)
+    while True:
+        p, contigs, y = random_case(rng, big=(seed % 12 == 0))
+        if local16_eligible(p):
+            break
+    compare_local(p, contigs, y, rng)
