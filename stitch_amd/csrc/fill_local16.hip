@@ -171,8 +171,13 @@ __device__ __forceinline__ void tile(const JobView& V, const DpParams& P, WaveCo
 
 }  // namespace
 
-__global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __restrict__ jobs, FillShared sh) {
-    const JobView& V = jobs[blockIdx.x];
+// G workgroups cooperate on one read: workgroup `part` owns the active contigs k = part, part+G, ... and exchanges its
+// contigs' column arg-max (the next column's jump sources) with the others through 8-byte {data, tag} granules in
+// global memory (agent-scope relaxed atomics: the tag travels with the data, so no fence is needed; double-buffered by
+// column parity).  All G workgroups of a read must be resident at once: the host keeps the grid <= the CU count.
+__global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __restrict__ jobs, FillShared sh, uint32_t G) {
+    const JobView& V = jobs[blockIdx.x / G];
+    const uint32_t part = blockIdx.x % G;
     const DpParams P = V.P;
     const uint32_t n = V.n, nact = V.nact, Rtot = V.Rtot;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
@@ -184,11 +189,14 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
     __shared__ int32_t rowm_S[MAXC]; __shared__ uint32_t rowm_len[MAXC];
     __shared__ int32_t s_vrun[MAXC];
     __shared__ uint32_t s_act[MAXC]; __shared__ int32_t s_opp[MAXC];
+    __shared__ uint32_t s_abort;
 
     uint32_t* __restrict__ st = V.st16;
+    unsigned long long* __restrict__ xchg = V.xchg;      // [2][C][2] granules
+    if (threadIdx.x == 0) s_abort = 0;
 
     // ---- column 0 (init_matrices :97-186) ---------------------------------------------------------------------
-    for (uint32_t k = 0; k < nact; ++k) {
+    for (uint32_t k = part; k < nact; k += G) {
         const uint32_t c = V.act[k];
         const uint32_t roff = V.cd[c].roff, troff = V.cd[c].troff;
         const uint32_t mpad = (V.cd[c].m + TILE - 1) / TILE * TILE;
@@ -207,14 +215,14 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
         base[c] = sh.base0[c];
         s_vrun[c] = sh.base0[c].score;
         rowm_xsuf[c] = sh.Smove0[trm] == TB_XCLIP_SUFFIX; rowm_S[c] = sh.S0[trm]; rowm_len[c] = sh.Slen0[trm];
-        V.Lx[(size_t)c * (n + 1)] = sh.lx0[c];
+        if (k % G == part) V.Lx[(size_t)c * (n + 1)] = sh.lx0[c];
     }
     for (uint32_t c = threadIdx.x; c < V.C; c += blockDim.x) s_opp[c] = V.opp_act[c];
     __syncthreads();
 
     for (uint32_t j = 1; j <= n; ++j) {
         // per-contig best jump out of column j-1 (multi_contig_aligner.rs:280-331): one thread per contig
-        for (uint32_t k = threadIdx.x; k < nact; k += blockDim.x) {
+        for (uint32_t k = part + threadIdx.x * G; k < nact; k += blockDim.x * G) {
             const uint32_t c = s_act[k];
             const JumpInfo ji = select_jump(P, base, s_act, nact, c, s_opp[c]);
             ColCtx cx; cx.jump = ji; cx.circ_ok = (P.circular && !rowm_xsuf[c]) ? 1 : 0; cx.circ_score = rowm_S[c]; cx.circ_len = rowm_len[c] + 1;
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
         uint8_t* __restrict__ tbcol = V.tb + (size_t)(j - 1) * Rtot;
         const uint8_t q = V.y[j - 1];
 
-        for (uint32_t k = wave; k < nact; k += W) {
+        for (uint32_t k = part + wave * G; k < nact; k += W * G) {
             const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_act[k]);
             const ContigDesc cd = V.cd[c];
             const uint32_t m = cd.m, roff = cd.roff;
@@ -310,17 +318,43 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
                     }
                     JumpBase b; b.score = cb_.v; b.len = cb_.len + 1; b.from = cb_.row;
                     base[c] = b;
+                    if (G > 1) {
+                        unsigned long long* g = xchg + ((size_t)(j & 1) * V.C + c) * 2;
+                        __hip_atomic_store(g, ((unsigned long long)j << 32) | (uint32_t)b.score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(g + 1, ((unsigned long long)j << 32) | (b.len << 16) | b.from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     if (cb_.v > wc.vrun) s_vrun[c] = cb_.v;
                     rowm_xsuf[c] = mvm == MK_XSUF; rowm_S[c] = Sm; rowm_len[c] = Slm;
                 }
             }
         }
         __syncthreads();
+        if (G > 1) {
+            // gather the other workgroups' records of column j (bounded spin: a missing partner must not hang the GPU)
+            for (uint32_t k = threadIdx.x; k < nact; k += blockDim.x) {
+                if (k % G == part) continue;
+                const uint32_t c = s_act[k];
+                const unsigned long long* g = xchg + ((size_t)(j & 1) * V.C + c) * 2;
+                const unsigned long long t0 = wall_clock64();
+                unsigned long long a, b;
+                for (;;) {
+                    a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(a >> 32) == j && (uint32_t)(b >> 32) == j) break;
+                    if (wall_clock64() - t0 > 400000000ull) { s_abort = 1; break; }      // 4 s at 100 MHz
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                JumpBase r; r.score = (int32_t)(uint32_t)a; r.len = ((uint32_t)b >> 16) & 0xFFFFu; r.from = (uint32_t)b & 0xFFFFu;
+                base[c] = r;
+            }
+            __syncthreads();
+            if (s_abort) { if (threadIdx.x == 0) *V.err = 1; return; }
+        }
     }
 }
 
-void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillShared& sh, hipStream_t stream) {
-    hipLaunchKernelGGL(fill_local16_kernel, dim3(n_jobs), dim3(waves * 64), 0, stream, d_jobs, sh);
+void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, const FillShared& sh, hipStream_t stream) {
+    hipLaunchKernelGGL(fill_local16_kernel, dim3(n_jobs * G), dim3(waves * 64), 0, stream, d_jobs, sh, G);
 }
 
 }  // namespace stitch

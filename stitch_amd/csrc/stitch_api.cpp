@@ -31,7 +31,7 @@ struct FillShared {
 void launch_fill(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillShared& sh, hipStream_t stream);
 void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, hipStream_t stream);
 constexpr uint32_t TILE_ROWS = 512;   // 64 lanes x 8 rows (Local-mode kernel; the generic one uses 256): contig row blocks are padded to this
-void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillShared& sh, hipStream_t stream);
+void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, const FillShared& sh, hipStream_t stream);
 }  // namespace stitch
 
 using namespace stitch;
@@ -76,6 +76,7 @@ struct stitch_ctx {
     std::vector<stitch_read_result> rr; std::vector<stitch_chain> chains; std::vector<stitch_op> ops;
     std::vector<std::vector<HAln>> per_read;     // for stitch_format_sam
     stitch_timing tm{};
+    int n_cus = 256; uint32_t tm_wg_per_read = 1;
     bool tm_fast = false;                        // last run_jobs used the Local-mode 16-bit kernel
     size_t mem_limit = 0;                        // optional cap on arena bytes (STITCH_ARENA_BYTES), for tests
 };
@@ -246,6 +247,7 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     if ((rc = upload(&c->d_xseq, xseq)) || (rc = upload(&c->d_S0, S0)) || (rc = upload(&c->d_Slen0, Slen0)) || (rc = upload(&c->d_Sn0, Sn0)) ||
         (rc = upload(&c->d_SnSet0, SnSet0)) || (rc = upload(&c->d_Smove0, Smove0)) || (rc = upload(&c->d_Imove0, Imove0)) ||
         (rc = upload(&c->d_lx0, lx0)) || (rc = upload(&c->d_base0, base0))) return rc;
+    { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal)); c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
     HIP_TRY(hipStreamCreate(&c->stream));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     if (const char* lim = getenv("STITCH_ARENA_BYTES")) c->mem_limit = (size_t)strtoull(lim, nullptr, 10);
@@ -263,7 +265,7 @@ namespace {
 struct JobLayout {
     uint32_t n, nact, Rj, slots, ops_cap;
     size_t off_S, off_Slen, off_D, off_Dlen, off_Sn, off_SnLen, off_Ly, off_Ival, off_Ilen, off_SidxF, off_SfromF, off_SmoveF, off_ImoveF,
-        off_st16, off_tb, off_Lx, off_jti, off_jtf, off_Sm, off_Lm, off_y, off_act, off_opp, off_cd, off_hdr, off_ops, bytes;
+        off_st16, off_xchg, off_tb, off_Lx, off_jti, off_jtf, off_Sm, off_Lm, off_y, off_act, off_opp, off_cd, off_hdr, off_ops, bytes;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -282,6 +284,7 @@ JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
     L.off_Ival = take(4ull * R); L.off_Ilen = take(4ull * R); L.off_SidxF = take(4ull * R); L.off_SfromF = take(4ull * R);
     L.off_SmoveF = take(R); L.off_ImoveF = take(R);
     L.off_st16 = take(8ull * R);
+    L.off_xchg = take(32ull * c.C + 256);      // 2 parities x C contigs x two 8-byte granules, then the error word
     L.off_tb = take((size_t)L.n * R);
     L.off_Lx = take(4ull * c.C * (L.n + 1)); L.off_jti = take(4ull * c.C * (L.n + 1)); L.off_jtf = take(4ull * c.C * (L.n + 1));
     L.off_Sm = take(4ull * c.C); L.off_Lm = take(4ull * c.C);
@@ -336,7 +339,8 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
         // greedy pack of consecutive jobs into the arena
         size_t k1 = k0, used = 0;
         const size_t view_room = 1 << 20;
-        while (k1 < jobs.size() && used + lay[k1].bytes + view_room <= c.arena_bytes && (k1 - k0) < 4096) { used += lay[k1].bytes; ++k1; }
+        const size_t max_jobs = fast ? (size_t)c.n_cus : 4096;      // co-residency of the Local-mode kernel's workgroups
+        while (k1 < jobs.size() && used + lay[k1].bytes + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].bytes; ++k1; }
         if (k1 == k0) return fail(STITCH_ENOMEM, "arena too small for one job");
         const uint32_t nj = (uint32_t)(k1 - k0);
         std::vector<JobView> views(nj); std::vector<WalkArgs> wargs(nj);
@@ -372,6 +376,8 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
             V.xseq = c.d_xseq; V.y = B + L.off_y;
             V.S = (int32_t*)(B + L.off_S); V.Slen = (uint32_t*)(B + L.off_Slen); V.D = (int32_t*)(B + L.off_D); V.Dlen = (uint32_t*)(B + L.off_Dlen);
             V.st16 = (uint32_t*)(B + L.off_st16);
+            V.xchg = (unsigned long long*)(B + L.off_xchg); V.err = (uint32_t*)(B + L.off_xchg + 32ull * c.C);
+            HIP_TRY(hipMemsetAsync(B + L.off_xchg, 0, 32ull * c.C + 256, c.stream));
             V.Sn = (int32_t*)(B + L.off_Sn); V.SnLen = (uint32_t*)(B + L.off_SnLen); V.Ly = (uint32_t*)(B + L.off_Ly);
             V.tb = B + L.off_tb; V.Lx = (uint32_t*)(B + L.off_Lx); V.jt_idx = (uint32_t*)(B + L.off_jti); V.jt_from = (uint32_t*)(B + L.off_jtf);
             V.Ival = (int32_t*)(B + L.off_Ival); V.Ilen = (uint32_t*)(B + L.off_Ilen); V.SmoveF = B + L.off_SmoveF;
@@ -393,7 +399,21 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
 
         // Kernel 1 and 2, timed with events on the stream they run on
         HIP_TRY(hipEventRecord(c.ev[0], c.stream));
-        if (fast) launch_fill_local16(d_views, nj, waves, sh, c.stream);
+        // workgroups per read for the Local-mode kernel: fill the CUs, but keep every workgroup resident at once (they
+        // wait for each other every column) and leave each at least a couple of contigs
+        uint32_t G = 1;
+        if (fast) {
+            uint32_t min_act = 0xFFFFFFFFu;
+            for (uint32_t q = 0; q < nj; ++q) min_act = std::min(min_act, lay[k0 + q].nact);
+            const uint32_t cus = (uint32_t)c.n_cus;
+            G = std::max(1u, std::min({cus / nj, (min_act + 1) / 2, 16u}));
+            if (const char* g = getenv("STITCH_WG_PER_READ")) G = std::max(1u, (uint32_t)atoi(g));
+            if (nj * G > cus) G = std::max(1u, cus / nj);
+            uint32_t max_act = 0; for (uint32_t q = 0; q < nj; ++q) max_act = std::max(max_act, lay[k0 + q].nact);
+            waves = pick_waves((max_act + G - 1) / G);
+        }
+        c.tm_wg_per_read = G;
+        if (fast) launch_fill_local16(d_views, nj, G, waves, sh, c.stream);
         else launch_fill(d_views, nj, waves, sh, c.stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev[1], c.stream));
@@ -406,6 +426,10 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
         HIP_TRY(hipEventElapsedTime(&ms, c.ev[0], c.ev[1])); c.tm.fill_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, c.ev[1], c.ev[2])); c.tm.walk_ms += ms;
         c.tm.launches += 1; c.tm.jobs += nj;
+        if (fast && G > 1) for (uint32_t q = 0; q < nj; ++q) {
+            uint32_t e = 0; HIP_TRY(hipMemcpy(&e, views[q].err, 4, hipMemcpyDeviceToHost));
+            if (e) return fail(STITCH_EINTERNAL, "a workgroup timed out waiting for its partners (workgroups of one read were not co-resident)");
+        }
 
         // download chains
         auto t_d2h0 = std::chrono::steady_clock::now();

@@ -35,6 +35,8 @@ struct JobView {
     const uint8_t* y;          // read bases, upper-cased
     // per-read row state, [Rtot] each; after the fill they hold column n
     int32_t* S; uint32_t* Slen; int32_t* D; uint32_t* Dlen; int32_t* Sn; uint32_t* SnLen; uint32_t* Ly;
+    unsigned long long* xchg;  // [2][C][2] inter-workgroup exchange granules of the Local-mode kernel (zeroed before launch)
+    uint32_t* err;             // set to 1 if the kernel gave up waiting for a partner workgroup
     uint32_t* st16;            // [2*Rtot] packed row state of the Local-mode kernel: {S | S.len<<16, D | D.len<<16}
     uint8_t* tb;               // [n][Rtot] traceback bytes, column j at (j-1)*Rtot
     uint32_t* Lx;              // [C][n+1]
