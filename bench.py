@@ -98,7 +98,7 @@ def main():
         torch.cuda.synchronize()
 
     for s in range(args.warmup):
-        aligners.align_packed(*batches[s])
+        aligners.align_packed_raw(*batches[s])
     sync()
     t0 = time.perf_counter()
     fill_ms = walk_ms = 0.0
@@ -106,10 +106,10 @@ def main():
     launches = 0
     mapped = 0
     for s in range(args.warmup, total_steps):
-        res = aligners.align_packed(*batches[s])
+        rr, ch, _ops = aligners.align_packed_raw(*batches[s])       # result arena views: what a compiled front end would read
         tm = aligners.timing()
         fill_ms += tm["fill_ms"]; walk_ms += tm["walk_ms"]; cells += tm["cells"]; launches += tm["launches"]
-        mapped += sum(1 for ch, _ in res if ch and ch[0].score >= 100)
+        mapped += int((ch["score"][rr["chains_begin"][rr["n_chains"] > 0]] >= 100).sum())
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -131,14 +131,14 @@ def main():
         out = {
             "metric": "reads_per_sec", "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
+            "dtype": "int16 scores and lengths packed in int32 words", "data": "synthetic",
             "config": {"workload": f"{args.read_len} bp chimeric ONT-like reads vs {args.contigs}x{args.contig_len} bp construct DB, "
                                    "local mode, single strand (BASELINE configs[1])",
                        "reads_per_step_per_gpu": R, "cells_per_read": args.read_len * args.contigs * args.contig_len,
                        "scoring": "A=1 B=-4 O=-6 E=-2 J=-10", "sharding": "reads by rank, index broadcast once"},
             "gcells_per_sec": cells_all / dt / 1e9,
             "mapped_fraction": mapped / float(R * args.steps),
-            "roofline": {"bound": "hbm", "kernel": "stitch::fill_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "stitch::fill_local16_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_cell": 1.0, "cells_per_launch": cells / max(1, launches),
                          "avg_launch_ms": fill_ms / max(1, launches), "walk_kernel_ms_per_step": walk_ms / args.steps,

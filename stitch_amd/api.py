@@ -288,6 +288,26 @@ class Aligners:
             out.append((chains, int(rr[r].prealign_score) if rr[r].has_prealign else None))
         return out
 
+    def align_packed_raw(self, bases, offsets):
+        """Same call without building Python objects: returns (read_results, chains, ops) as numpy structured-array VIEWS
+        of the library's result arena (valid until the next call).  This is what a compiled front end would consume."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        rr, ch, op = C.POINTER(_ReadResult)(), C.POINTER(_Chain)(), C.POINTER(_Op)()
+        cells = C.c_uint64(0)
+        _check(lib().stitch_align_batch(self.h, bases.ctypes.data_as(C.POINTER(C.c_uint8)), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        C.c_uint32(n), C.byref(rr), C.byref(ch), C.byref(op), C.byref(cells)))
+        self.cells_filled = int(cells.value)
+        if n == 0:
+            return np.zeros(0, dtype=_ReadResult), np.zeros(0, dtype=_Chain), np.zeros(0, dtype=_Op)
+        rr_a = np.ctypeslib.as_array(rr, shape=(n,))
+        n_ch = int(rr_a["chains_begin"][-1] + rr_a["n_chains"][-1])
+        ch_a = np.ctypeslib.as_array(ch, shape=(n_ch,)) if n_ch else np.zeros(0, dtype=_Chain)
+        n_op = int(ch_a["ops_begin"][-1] + ch_a["ops_len"][-1]) if n_ch else 0
+        op_a = np.ctypeslib.as_array(op, shape=(n_op,)) if n_op else np.zeros(0, dtype=_Op)
+        return rr_a, ch_a, op_a
+
     def align_one(self, read):
         return self.align([read])[0]
 

@@ -201,48 +201,12 @@ STITCH_HD void row_phase_c(const DpParams& P, const ColCtx& cx, uint32_t i, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Local-mode selection by ordered keys (used by fill_local16.hip and its CPU emulation).
+// Local-mode kernel (fill_local16.hip and its CPU emulation).
 //
-// In Local mode the reference's chain of `if candidate > best` tests (:355-399) is a maximum under a total
-// order: higher score first, then the earlier candidate in the reference's order.  Encoding each candidate as
-//   key = score * 8 + priority        priority: diagonal 5 > deletion 4 > insertion 3 > jump 2 > x-prefix clip 1
-// turns the chain into integer max operations.  The one exception — a jump that ties with the DIAGONAL wins if its
-// alignment is longer (:374-377) — is the jump getting priority 6 exactly when J == diag && J.len > diag.len:
-// if some other candidate is strictly better than the diagonal the jump cannot tie with the best anyway, and if
-// the deletion/insertion merely tie with the diagonal the reference keeps the diagonal (they need `>`), so
-// `best == diag` holds and the rule applies.  The priorities double as the traceback byte's move code.
+// Move codes of the Local-mode kernel's traceback bytes (bits 0-2; IEXT/DEXT as in the generic format).
 // ------------------------------------------------------------------------------------------------------------
 enum : uint32_t { MK_XSUF = 0, MK_XPRE = 1, MK_JUMP = 2, MK_INS = 3, MK_DEL = 4, MK_DIAG = 5, MK_JUMPL = 6 };
-constexpr int32_t KEY_SCORE_FLOOR = -(1 << 27);    // scores below this are clamped before the * 8 (only MIN-seeded chains)
 
-struct RowK { int32_t Tk; uint32_t Tl; int32_t bd; uint32_t dlen; uint32_t dext; int32_t dg; };
-
-// js/jl: the jump candidate's score without the match term and its length (for row 1 of a circular contig the
-// caller passes the better of the column's jump and the end-to-start jump, see local_row1_jump).
-STITCH_HD void row_phase_a_key(const DpParams& P, uint8_t p, uint8_t q, int32_t js, uint32_t jl, int32_t Sp_up, uint32_t Slp_up,
-                               int32_t Sp, uint32_t Slp, int32_t Dp, uint32_t Dlp, RowK& r) {
-    const int32_t a = (p == q) ? P.match : P.mismatch;
-    const int32_t de = Dp + P.gap_extend;
-    const int32_t dop = Sp + P.gap_open + P.gap_extend;
-    r.bd = de > dop ? de : dop;
-    r.dext = (de == r.bd);
-    r.dlen = (r.dext ? Dlp : Slp) + 1;
-    r.dg = Sp_up + a; const uint32_t dl = Slp_up + 1;
-    const int32_t J = js + a;
-    const int32_t dgk = r.dg * 8 + (int32_t)MK_DIAG, bdk = r.bd * 8 + (int32_t)MK_DEL;
-    const int32_t Jk = J * 8 + (int32_t)((J == r.dg && jl > dl) ? MK_JUMPL : MK_JUMP);
-    int32_t k = dgk > bdk ? dgk : bdk; k = k > Jk ? k : Jk; k = k > (int32_t)MK_XPRE ? k : (int32_t)MK_XPRE;
-    r.Tk = k;
-    r.Tl = k == dgk ? dl : k == bdk ? r.dlen : k == (int32_t)MK_XPRE ? 0u : jl;
-}
-// merges the insertion: returns the final key; S = key >> 3 (arithmetic), move = key & 7
-STITCH_HD int32_t row_phase_c_key(const RowK& r, int32_t bi, uint32_t il, uint32_t& Sl) {
-    const int32_t bic = bi > KEY_SCORE_FLOOR ? bi : KEY_SCORE_FLOOR;
-    const int32_t bik = bic * 8 + (int32_t)MK_INS;
-    const int32_t k = r.Tk > bik ? r.Tk : bik;
-    Sl = k == bik ? il : r.Tl;
-    return k;
-}
 // Row 1 of a circular contig may take the zero-cost jump from row m of the previous column instead of the column's
 // best jump (get_jump_score_and_len :258-289).  Both candidates get the same match term added, so the choice does
 // not depend on the bases and is made once per (contig, column).
@@ -263,6 +227,57 @@ STITCH_HD uint32_t key_code_to_generic(uint32_t code, bool row1_circ) {
         case MK_DIAG: return MV_DIAG | bits;
         default: return (row1_circ ? MV_CIRC : MV_JUMP) | bits;      // MK_JUMP, MK_JUMPL
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Local-mode selection on combined words (fill_local16.hip's inner loop).
+//
+// A candidate is ONE signed 32-bit word  w = score << 16 | len  (len < 65535, |score| < 32768): signed comparison
+// orders by score, then by alignment length; adding (delta << 16) + 1 advances score and length together; w | 0xFFFF
+// is the largest word with w's score, so `x > (w | 0xFFFF)` is "x.score > w.score".  The row state is stored in this
+// form, so nothing is unpacked or packed.  The reference's rules in this form (single_contig_aligner.rs:328-399):
+//   deletion   de vs open: extension wins ties (:332)           -> (DE | 0xFFFF) >= DO
+//   S order    diag, then deletion / insertion / x-prefix clip only if STRICTLY better in score (:357-389)
+//   jump       beats the running best if better in score, or — when the running best is still the diagonal — if it
+//              ties in score with a longer alignment (:374-377): exactly `JW > DG` as words
+// ------------------------------------------------------------------------------------------------------------
+struct RowW { int32_t T; uint32_t mvT; int32_t BD; uint32_t dext; int32_t DG; int32_t bs2h; int32_t JW; };
+
+STITCH_HD int32_t word_make(int32_t score, uint32_t len) { return (int32_t)(((uint32_t)score << 16) | (len & 0xFFFFu)); }
+STITCH_HD int32_t word_score(int32_t w) { return w >> 16; }
+STITCH_HD uint32_t word_len(int32_t w) { return (uint32_t)w & 0xFFFFu; }
+
+// aw = match_fn.score << 16; GE1 = (ge << 16) + 1; GO1 = ((go + ge) << 16) + 1; JSW = word of the column's jump without
+// the match term (for row 1 of a circular contig: of the better of it and the end-to-start jump)
+STITCH_HD void row_phase_a_word(int32_t aw, int32_t GE1, int32_t GO1, int32_t JSW, int32_t Sup, int32_t Sp, int32_t Dp, RowW& r) {
+    r.DG = Sup + aw + 1;
+    const int32_t DE = Dp + GE1, DO = Sp + GO1;
+    r.dext = (DE | 0xFFFF) >= DO;
+    r.BD = r.dext ? DE : DO;
+    const int32_t DGh = r.DG | 0xFFFF, BDh = r.BD | 0xFFFF;
+    const bool c1 = r.BD > DGh;                       // deletion strictly better than the diagonal
+    const int32_t bs2 = c1 ? r.BD : r.DG;
+    r.bs2h = c1 ? BDh : DGh;
+    r.JW = JSW + aw;
+    const int32_t X = c1 ? BDh : r.DG;                // what the jump has to beat
+    const bool c3 = r.JW > X;
+    int32_t T = c3 ? r.JW : bs2;
+    const bool c4 = T < 0;                            // x-prefix clip: score 0, length 0
+    r.T = c4 ? 0 : T;
+    r.mvT = c4 ? MK_XPRE : c3 ? MK_JUMP : c1 ? MK_DEL : MK_DIAG;
+}
+// merges the insertion (score bi, length il); returns the final word, `mv` its move
+STITCH_HD int32_t row_phase_c_word(const RowW& r, int32_t bi, uint32_t il, uint32_t& mv) {
+    const int32_t bic = bi > -16384 ? bi : -16384;    // only chains seeded with MIN get here: keep the word in range
+    const int32_t BI = word_make(bic, il);
+    const bool c2 = BI > r.bs2h;                      // insertion strictly better than {diag, deletion}
+    const bool c5 = r.JW > (BI | 0xFFFF);
+    int32_t F1 = c5 ? r.JW : BI;
+    const bool c6 = F1 < 0;
+    F1 = c6 ? 0 : F1;
+    const uint32_t mv1 = c6 ? MK_XPRE : c5 ? MK_JUMP : MK_INS;
+    mv = c2 ? mv1 : r.mvT;
+    return c2 ? F1 : r.T;
 }
 
 // Phase B: the insertion chain as a prefix max.  Row i may open from row i-1 with o_i = S'(i-1)+go+ge, where S' is

@@ -29,9 +29,57 @@ struct FillShared {
 
 namespace {
 
+// In-kernel stamps (diagnostic build only, -DSTITCH_PROFILE): per-wave cycle sums of the column loop's sections, written to
+// the debug area behind V.err.  Never enabled in the product build.
+#ifdef STITCH_PROFILE
+#define PROF_DECL unsigned long long pf_t = __builtin_readcyclecounter(), pf_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF(k) { unsigned long long pf_n = __builtin_readcyclecounter(); pf_sum[k] += pf_n - pf_t; pf_t = pf_n; }
+#else
+#define PROF_DECL
+#define PROF(k)
+#endif
+
+// Pointers loaded from the JobView are generic ("flat") to the compiler; flat loads cannot be waited for with a counted
+// vmcnt (cdna_hip_programming.md: flat_* return out of order), which would serialise the software pipeline.  Casting them
+// to address space 1 once makes every access a global_load/global_store.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vectors: HIP's u32x4 class has no address-space-1 overloads
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <typename T> using gptr = T __attribute__((address_space(1)))*;
+template <typename T> __device__ __forceinline__ gptr<T> as_global(T* p) { return (gptr<T>)(uintptr_t)p; }
+
+struct GPtrsCold {            // pointers of the rare paths live in LDS, not in (scarce) SGPRs
+    gptr<int32_t> Sn, S, Ival; gptr<uint32_t> SnLen, Ly, Slen, Ilen, Lx, jt_idx, jt_from;
+    gptr<unsigned long long> xchg;
+};
+struct GPtrs {                // hot pointers, kept in registers
+    gptr<uint32_t> st; gptr<const uint8_t> xseq; gptr<uint8_t> tb;
+    const GPtrsCold* cold;    // in LDS
+};
+
+// Software pipeline of the tile loop.  hipcc cannot count vmcnt across this loop (conditional memory operations in the body
+// make it fall back to vmcnt(0), which also waits for the prefetch it has just issued), so the state prefetch is issued and
+// waited for by hand (cdna_hip_programming.md §5.7): loads of the NEXT tile are issued right after the wait for the current
+// one; when they are needed the only younger vector-memory operations that must be allowed to stay in flight are the 5
+// stores of the tile computed in between (4 x 16 B state + 8 B traceback), hence vmcnt(5).  Extra (conditional) operations
+// only make the wait stricter.
+struct TileRegs { u32x4 v0, v1, v2, v3; u32x2 x; };
+__device__ __forceinline__ void tile_load(TileRegs& r, gptr<const u32x4> p, gptr<const u32x2> px) {
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                 : "=&v"(r.v0), "=&v"(r.v1), "=&v"(r.v2), "=&v"(r.v3) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(r.x) : "v"(px) : "memory");
+}
+__device__ __forceinline__ void tile_wait(TileRegs& r) {
+    asm volatile("s_waitcnt vmcnt(5)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.v2), "+v"(r.v3), "+v"(r.x) : : "memory");
+}
+__device__ __forceinline__ void tile_wait_all(TileRegs& r) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.v2), "+v"(r.v3), "+v"(r.x) : : "memory");
+}
+
 constexpr int MAXC = 256;
 constexpr int R = 8;
 constexpr uint32_t TILE = 64 * R;
+constexpr uint32_t MAXSLOTS = 4096, SLOT_FIRST = 0x40000000u, SLOT_LAST = 0x80000000u;   // slot = contig | tile<<8 | flags
 constexpr int DPP_ROW_SHR0 = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;
 
 template <int CTRL, int ROW_MASK = 0xF>
@@ -58,60 +106,68 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     for (int d = 32; d >= 1; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
     return v;
 }
-__device__ __forceinline__ uint32_t pk16(int32_t v, uint32_t len) { return ((uint32_t)v << 16) | (len & 0xFFFFu); }
+
+// Rows of a tile are independent, and the scheduler would interleave all eight of them: dozens of compare masks (SGPR
+// pairs) live at once, far beyond the 102 SGPRs of a wave, i.e. v_writelane/v_readlane spill traffic in the inner loop.
+// At two waves per SIMD a wave only gets every other issue slot anyway, so nothing is lost by finishing one row before the
+// next: the fence keeps the schedule row-serial.
+#ifndef STITCH_NO_ROW_FENCE
+#define ROW_FENCE __builtin_amdgcn_sched_barrier(0);
+#else
+#define ROW_FENCE
+#endif
 
 struct WaveCol {                 // wave-uniform state of one contig's column
-    int32_t js; uint32_t jl;     // column's best jump (score without the match term, length)
-    int32_t js1; uint32_t jl1;   // same for row 1 (circular contigs may use the end-to-start jump)
+    int32_t JSW, JSW1;           // word of the column's best jump without the match term; same for row 1 (circular contigs)
     int32_t vrun;                // contig's running maximum up to column j-1
     uint32_t m, roff, j, n;
-    uint8_t q;
-    int32_t upS, upT; uint32_t upSl, upTl;      // carries: S[prev][i0-1], its len; S'[curr][i0-1], its len
+    uint32_t q;
+    int32_t upS, upT;            // carries (words): S[prev][i0-1] and S'[curr][i0-1]
     ScanEl carry;
 };
 struct LaneAcc {                 // per-lane running records over a contig's column (rows < m)
-    uint32_t xw, xrow;           // best S<<16|len and its (lowest) row: the x-suffix running max (:406-429)
+    uint32_t xw, xrow;           // best S word and its (lowest) row: the x-suffix running max (:406-429)
     uint32_t ck;                 // max of S<<16 | (0xFFFF - row): column arg-max, lowest row (:677-697)
 };
-struct RowM { int32_t key; uint32_t Sl, bits, dpack; int32_t dg; };   // row m's own selection, finalised after the reduction
+struct RowM { int32_t F; uint32_t mv, bits; int32_t BD, DG; };   // row m's own selection, finalised after the reduction
+struct WordConsts { int32_t MW, XW, GE1, GO1, ge, kb0; };        // match/mismatch << 16, gap words, ge, go + ge
 
-// One 512-row tile.  PARTIAL: the contig's last tile (rows may exceed m, and row m is held back).  LASTCOL: j == n,
-// the int32 arrays the fix-up kernel reads are written as well.
-template <bool PARTIAL, bool LASTCOL>
-__device__ __forceinline__ void tile(const JobView& V, const DpParams& P, WaveCol& wc, LaneAcc& acc, RowM& rm, const uint4 (&cur)[4], uint2 curx,
-                                     uint32_t t, int lane, uint32_t* __restrict__ st, uint8_t* __restrict__ tbcol) {
+// One 512-row tile.  PARTIAL: the contig's last tile (rows may exceed m, and row m is held back).  LASTCOL (wave-uniform,
+// run time): j == n, the int32 arrays the fix-up kernel reads are written as well.
+template <bool PARTIAL>
+__device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, WaveCol& wc, LaneAcc& acc, RowM& rm, const TileRegs& tr, bool LASTCOL,
+                                     uint32_t t, int lane, gptr<uint8_t> tbcol) {
+    const u32x4 cur[4] = {tr.v0, tr.v1, tr.v2, tr.v3}; const u32x2 curx = tr.x;
     const uint32_t i0 = t * TILE + lane * R + 1;
     const uint32_t r = wc.roff + i0 - 1;
     const uint32_t m = wc.m;
-    int32_t Sp[R], Dp[R]; uint32_t Slp[R], Dlp[R]; uint32_t xb[R];
+    int32_t Sp[R], Dp[R]; uint32_t xb[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) {
-        const uint32_t w0 = (u & 1) ? cur[u >> 1].z : cur[u >> 1].x, w1 = (u & 1) ? cur[u >> 1].w : cur[u >> 1].y;
-        Sp[u] = (int32_t)(w0 >> 16); Slp[u] = w0 & 0xFFFFu;
-        Dp[u] = (int32_t)w1 >> 16; Dlp[u] = w1 & 0xFFFFu;
+        Sp[u] = (int32_t)((u & 1) ? cur[u >> 1].z : cur[u >> 1].x); Dp[u] = (int32_t)((u & 1) ? cur[u >> 1].w : cur[u >> 1].y);
         xb[u] = ((u < 4 ? curx.x : curx.y) >> (8 * (u & 3))) & 0xFFu;
     }
-    const int32_t nS = from_prev_lane(Sp[R - 1], wc.upS); const uint32_t nSl = (uint32_t)from_prev_lane((int)Slp[R - 1], (int)wc.upSl);
-    wc.upS = lane_bcast(Sp[R - 1], 63); wc.upSl = (uint32_t)lane_bcast((int)Slp[R - 1], 63);
+    const int32_t nS = from_prev_lane(Sp[R - 1], wc.upS);
+    wc.upS = lane_bcast(Sp[R - 1], 63);
 
-    RowK ra[R];
+    RowW ra[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) {
         const bool row1 = (u == 0) && (i0 == 1);
-        row_phase_a_key(P, (uint8_t)xb[u], wc.q, row1 ? wc.js1 : wc.js, row1 ? wc.jl1 : wc.jl, u == 0 ? nS : Sp[u - 1], u == 0 ? nSl : Slp[u - 1],
-                        Sp[u], Slp[u], Dp[u], Dlp[u], ra[u]);
+        row_phase_a_word(xb[u] == wc.q ? K.MW : K.XW, K.GE1, K.GO1, row1 ? wc.JSW1 : wc.JSW, u == 0 ? nS : Sp[u - 1], Sp[u], Dp[u], ra[u]);
+        ROW_FENCE
     }
     // phase B: insertion scan
-    const int32_t lastT = ra[R - 1].Tk >> 3;
-    const int32_t nT = from_prev_lane(lastT, wc.upT); const uint32_t nTl = (uint32_t)from_prev_lane((int)ra[R - 1].Tl, (int)wc.upTl);
-    wc.upT = lane_bcast(lastT, 63); wc.upTl = (uint32_t)lane_bcast((int)ra[R - 1].Tl, 63);
-    const int32_t kb = P.gap_open + P.gap_extend - P.gap_extend * (int32_t)i0;     // key_i = S'(i-1) + go + ge - ge*i
+    const int32_t nT = from_prev_lane(ra[R - 1].T, wc.upT);
+    wc.upT = lane_bcast(ra[R - 1].T, 63);
+    const int32_t kb = K.kb0 - K.ge * (int32_t)i0;                                  // key_i = S'(i-1) + go + ge - ge*i
     const int32_t qb = 1 - (int32_t)i0;                                             // q_i   = S'.len(i-1) + 1 - i
     ScanEl el[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) {
-        el[u].key = (u == 0 ? nT : (ra[u - 1].Tk >> 3)) + kb - P.gap_extend * u;
-        el[u].q = (int32_t)(u == 0 ? nTl : ra[u - 1].Tl) + qb - u;
+        const int32_t Tup = u == 0 ? nT : ra[u - 1].T;
+        el[u].key = word_score(Tup) + kb - K.ge * u;
+        el[u].q = (int32_t)word_len(Tup) + qb - u;
         if (PARTIAL && i0 + u > m) el[u].key = KEY_NEG_INF;
     }
     ScanEl inc = el[0];
@@ -122,51 +178,51 @@ __device__ __forceinline__ void tile(const JobView& V, const DpParams& P, WaveCo
     run = scan_combine(wc.carry, run);                                              // lane 0: INT32_MIN never wins -> carry
     { ScanEl last; last.key = lane_bcast(inc.key, 63); last.q = lane_bcast(inc.q, 63); wc.carry = scan_combine(wc.carry, last); }
     // phase C
-    const int32_t gi0 = P.gap_extend * (int32_t)i0;
-    uint32_t outw[2 * R]; uint32_t code[R]; uint32_t tk = 0;
+    const int32_t gi0 = K.ge * (int32_t)i0;
+    int32_t Fo[R]; uint32_t code[R]; uint32_t tk = 0;
 #pragma unroll
     for (int u = 0; u < R; ++u) {
         const uint32_t i = i0 + u;
         const uint32_t ext = run.key >= el[u].key ? 1u : 0u;
         if (!ext) run = el[u];
-        const int32_t bi = run.key + gi0 + P.gap_extend * u;
+        const int32_t bi = run.key + gi0 + K.ge * u;
         const uint32_t il = (uint32_t)(run.q + (int32_t)i0 + u);
-        uint32_t Slo;
-        const int32_t fk = row_phase_c_key(ra[u], bi, il, Slo);
-        const int32_t So = fk >> 3;
-        code[u] = ((uint32_t)fk & 7u) | (ext ? TBB_IEXT : 0u) | (ra[u].dext ? TBB_DEXT : 0u);
-        const uint32_t w = pk16(So, Slo);
-        outw[2 * u] = w; outw[2 * u + 1] = pk16(ra[u].bd, ra[u].dlen);
+        uint32_t mv;
+        const int32_t F = row_phase_c_word(ra[u], bi, il, mv);
+        code[u] = mv | (ext ? TBB_IEXT : 0u) | (ra[u].dext ? TBB_DEXT : 0u);
+        Fo[u] = F;
         if (!PARTIAL || i < m) {
-            const bool better = w > acc.xw;                                           // rows ascend within a lane: first max wins
-            acc.xw = better ? w : acc.xw; acc.xrow = better ? i : acc.xrow;
-            const uint32_t ck = ((uint32_t)So << 16) | (0xFFFFu - i);
+            const bool better = (uint32_t)F > acc.xw;                                 // rows ascend within a lane: first max wins (F >= 0)
+            acc.xw = better ? (uint32_t)F : acc.xw; acc.xrow = better ? i : acc.xrow;
+            const uint32_t ck = ((uint32_t)F & 0xFFFF0000u) | (0xFFFFu - i);
             tk = ck > tk ? ck : tk;
         }
         if (PARTIAL) {
-            if (i == m) { rm.key = fk; rm.Sl = Slo; rm.bits = code[u] & (TBB_IEXT | TBB_DEXT); rm.dpack = outw[2 * u + 1]; rm.dg = ra[u].dg; }
-            if (i > m) { outw[2 * u] = 0; outw[2 * u + 1] = pk16(-32768, 0); code[u] = 0; }
+            if (i == m) { rm.F = F; rm.mv = mv; rm.bits = code[u] & (TBB_IEXT | TBB_DEXT); rm.BD = ra[u].BD; rm.DG = ra[u].DG; }
+            if (i > m) { Fo[u] = 0; ra[u].BD = word_make(-16384, 0); code[u] = 0; }
         }
-        if (LASTCOL) { if (!PARTIAL || i <= m) { V.S[r + u] = So; V.Slen[r + u] = Slo; V.Ival[r + u] = bi; V.Ilen[r + u] = il; } }
+        if (LASTCOL) { if (!PARTIAL || i <= m) { const GPtrsCold& C = *V.cold; C.S[r + u] = word_score(F); C.Slen[r + u] = word_len(F); C.Ival[r + u] = bi; C.Ilen[r + u] = il; } }
+        ROW_FENCE
     }
     acc.ck = tk > acc.ck ? tk : acc.ck;
     // y-suffix trackers: only cells that reach the contig's running maximum can matter (:431-447)
     if ((int32_t)(tk >> 16) >= wc.vrun) {
+        const GPtrsCold& C = *V.cold;
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            const uint32_t i = i0 + u; const int32_t So = (int32_t)(outw[2 * u] >> 16); const uint32_t Slo = outw[2 * u] & 0xFFFFu;
+            const uint32_t i = i0 + u; const int32_t So = word_score(Fo[u]); const uint32_t Slo = word_len(Fo[u]);
             if ((!PARTIAL || i < m) && So >= wc.vrun && Slo > 0u) {
-                if (So >= V.Sn[r + u]) { V.Sn[r + u] = So; V.Ly[r + u] = wc.n - wc.j; V.SnLen[r + u] = Slo; }
+                if (So >= C.Sn[r + u]) { C.Sn[r + u] = So; C.Ly[r + u] = wc.n - wc.j; C.SnLen[r + u] = Slo; }
             }
         }
     }
-    uint4* __restrict__ stw = reinterpret_cast<uint4*>(st + 2 * (size_t)r);
+    gptr<u32x4> stw = (gptr<u32x4>)(V.st + 2 * (size_t)r);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) { uint4 o; o.x = outw[4 * v]; o.y = outw[4 * v + 1]; o.z = outw[4 * v + 2]; o.w = outw[4 * v + 3]; stw[v] = o; }
-    uint2 tbv;
+    for (int v = 0; v < 4; ++v) { u32x4 o; o.x = (uint32_t)Fo[2 * v]; o.y = (uint32_t)ra[2 * v].BD; o.z = (uint32_t)Fo[2 * v + 1]; o.w = (uint32_t)ra[2 * v + 1].BD; stw[v] = o; }
+    u32x2 tbv;
     tbv.x = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
     tbv.y = code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24);
-    *reinterpret_cast<uint2*>(tbcol + r) = tbv;
+    *(gptr<u32x2>)(tbcol + r) = tbv;
 }
 
 }  // namespace
@@ -190,9 +246,23 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
     __shared__ int32_t s_vrun[MAXC];
     __shared__ uint32_t s_act[MAXC]; __shared__ int32_t s_opp[MAXC];
     __shared__ uint32_t s_abort;
+    __shared__ uint32_t s_slots[MAXSLOTS]; __shared__ uint32_t s_wbeg[8], s_wend[8];
+    __shared__ uint32_t s_m[MAXC], s_roff[MAXC], s_seq[MAXC];
 
-    uint32_t* __restrict__ st = V.st16;
-    unsigned long long* __restrict__ xchg = V.xchg;      // [2][C][2] granules
+    __shared__ GPtrsCold s_cold;
+    if (threadIdx.x == 0) {
+        s_cold.Sn = as_global(V.Sn); s_cold.S = as_global(V.S); s_cold.Ival = as_global(V.Ival); s_cold.SnLen = as_global(V.SnLen);
+        s_cold.Ly = as_global(V.Ly); s_cold.Slen = as_global(V.Slen); s_cold.Ilen = as_global(V.Ilen); s_cold.Lx = as_global(V.Lx);
+        s_cold.jt_idx = as_global(V.jt_idx); s_cold.jt_from = as_global(V.jt_from); s_cold.xchg = as_global(V.xchg);   // [2][C][2] granules
+    }
+    GPtrs GP;
+    GP.st = as_global(V.st16); GP.xseq = as_global(V.xseq); GP.tb = as_global(V.tb); GP.cold = &s_cold;
+    const gptr<uint32_t> st = GP.st;
+    const uint32_t C = V.C;
+    WordConsts K;
+    K.MW = (int32_t)((uint32_t)P.match << 16); K.XW = (int32_t)((uint32_t)P.mismatch << 16);
+    K.GE1 = (int32_t)((uint32_t)P.gap_extend << 16) + 1; K.GO1 = (int32_t)((uint32_t)(P.gap_open + P.gap_extend) << 16) + 1;
+    K.ge = P.gap_extend; K.kb0 = P.gap_open + P.gap_extend;
     if (threadIdx.x == 0) s_abort = 0;
 
     // ---- column 0 (init_matrices :97-186) ---------------------------------------------------------------------
@@ -202,8 +272,8 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
         const uint32_t mpad = (V.cd[c].m + TILE - 1) / TILE * TILE;
         for (uint32_t i = threadIdx.x; i < mpad; i += blockDim.x) {
             const uint32_t r = roff + i, tr = troff + i;
-            st[2 * r] = pk16(sh.S0[tr], sh.Slen0[tr]);
-            st[2 * r + 1] = pk16(-32768, 0);                          // D = "MIN": never extends, never wins
+            st[2 * r] = (uint32_t)word_make(sh.S0[tr], sh.Slen0[tr]);
+            st[2 * r + 1] = (uint32_t)word_make(-16384, 0);            // D = "MIN": never extends, never wins, cannot wrap
             V.Sn[r] = sh.Sn0[tr]; V.SnLen[r] = sh.Slen0[tr]; V.Ly[r] = sh.SnSet0[tr] ? n : 0u;
             V.SmoveF[r] = TB_NONE; V.ImoveF[r] = TB_NONE;
         }
@@ -220,60 +290,83 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
     for (uint32_t c = threadIdx.x; c < V.C; c += blockDim.x) s_opp[c] = V.opp_act[c];
     __syncthreads();
 
+    // ---- per-wave slot table: the (contig, tile) pairs this wave walks every column, in order ---------------------
+    if (threadIdx.x == 0) {
+        uint32_t ns = 0;
+        for (int w = 0; w < W; ++w) {
+            s_wbeg[w] = ns;
+            for (uint32_t k = part + w * G; k < nact; k += W * G) {
+                const uint32_t c = V.act[k];
+                const uint32_t nt = (V.cd[c].m + TILE - 1) / TILE;
+                for (uint32_t t = 0; t < nt; ++t) if (ns < MAXSLOTS) s_slots[ns++] = c | (t << 8) | (t == 0 ? SLOT_FIRST : 0u) | (t + 1 == nt ? SLOT_LAST : 0u);
+            }
+            s_wend[w] = ns;
+        }
+    }
+    for (uint32_t k = threadIdx.x; k < nact; k += blockDim.x) { const uint32_t c = V.act[k]; s_m[c] = V.cd[c].m; s_roff[c] = V.cd[c].roff; s_seq[c] = V.cd[c].seqoff; }
+    __syncthreads();
+    const uint32_t sbeg = s_wbeg[wave], send = s_wend[wave];
+
+    // address of slot s's state / bases for this lane (slot index clamped: the pipeline always has a load in flight)
+    auto slot_ptrs = [&](uint32_t s, gptr<const u32x4>& ps, gptr<const u32x2>& px) {
+        s = s < send ? s : send - 1;
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slots[s]);
+        const uint32_t c = e & 0xFFu, t = (e >> 8) & 0x3FFFFFu;
+        const uint32_t roff = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_roff[c]), seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seq[c]);
+        const uint32_t o = t * TILE + lane * R;
+        ps = (gptr<const u32x4>)(st + 2 * (size_t)(roff + o));
+        px = (gptr<const u32x2>)(GP.xseq + seq + o);
+    };
+
+    PROF_DECL
     for (uint32_t j = 1; j <= n; ++j) {
-        // per-contig best jump out of column j-1 (multi_contig_aligner.rs:280-331): one thread per contig
+        PROF(0)
+        // per-contig best jump out of column j-1 (multi_contig_aligner.rs:280-331): one thread per own contig
         for (uint32_t k = part + threadIdx.x * G; k < nact; k += blockDim.x * G) {
             const uint32_t c = s_act[k];
-            const JumpInfo ji = select_jump(P, base, s_act, nact, c, s_opp[c]);
-            ColCtx cx; cx.jump = ji; cx.circ_ok = (P.circular && !rowm_xsuf[c]) ? 1 : 0; cx.circ_score = rowm_S[c]; cx.circ_len = rowm_len[c] + 1;
+            const JumpInfo ji = select_jump(V.P, base, s_act, nact, c, s_opp[c]);
+            ColCtx cx; cx.jump = ji; cx.circ_ok = (V.P.circular && !rowm_xsuf[c]) ? 1 : 0; cx.circ_score = rowm_S[c]; cx.circ_len = rowm_len[c] + 1;
             const bool circ = local_row1_circ(cx);
             s_jump[c] = ji; s_circ[c] = circ ? 1 : 0;
-            V.jt_idx[(size_t)c * (n + 1) + j] = ji.idx | (circ ? JT_CIRC_BIT : 0u);
-            V.jt_from[(size_t)c * (n + 1) + j] = ji.from;
+            s_cold.jt_idx[(size_t)c * (n + 1) + j] = ji.idx | (circ ? JT_CIRC_BIT : 0u);
+            s_cold.jt_from[(size_t)c * (n + 1) + j] = ji.from;
         }
+        PROF(1)
         __syncthreads();
+        PROF(2)
 
-        uint8_t* __restrict__ tbcol = V.tb + (size_t)(j - 1) * Rtot;
-        const uint8_t q = V.y[j - 1];
+        const gptr<uint8_t> tbcol = GP.tb + (size_t)(j - 1) * Rtot;
+        // readfirstlane forces the wait for this (compiler-visible) load here, outside the hand-pipelined tile loop
+        const uint8_t q = (uint8_t)__builtin_amdgcn_readfirstlane((int)V.y[j - 1]);
 
-        for (uint32_t k = part + wave * G; k < nact; k += W * G) {
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_act[k]);
-            const ContigDesc cd = V.cd[c];
-            const uint32_t m = cd.m, roff = cd.roff;
-            const uint8_t* __restrict__ xs = V.xseq + cd.seqoff;
-
-            WaveCol wc;
-            wc.js = s_jump[c].score; wc.jl = s_jump[c].len;
-            if (s_circ[c]) { wc.js1 = rowm_S[c]; wc.jl1 = rowm_len[c] + 1; } else { wc.js1 = wc.js; wc.jl1 = wc.jl; }
-            wc.vrun = s_vrun[c]; wc.m = m; wc.roff = roff; wc.j = j; wc.n = n; wc.q = q;
-            wc.upS = 0; wc.upSl = 0; wc.upT = 0; wc.upTl = 0;      // row 0 of a Local-mode column: S 0, length 0
-            wc.carry = scan_seed();
-            LaneAcc acc; acc.xw = 0; acc.xrow = 0; acc.ck = 0;
-            RowM rm; rm.key = 0; rm.Sl = 0; rm.bits = 0; rm.dpack = 0; rm.dg = 0;
-            const uint32_t ntiles = (m + TILE - 1) / TILE;
+        WaveCol wc; LaneAcc acc; RowM rm;
+        wc.j = j; wc.n = n; wc.q = (uint32_t)q;
+        const bool lastcol = (j == n);
+        uint32_t c = 0;
+        TileRegs A, B;
+        if (sbeg < send) { gptr<const u32x4> ps; gptr<const u32x2> px; slot_ptrs(sbeg, ps, px); tile_load(A, ps, px); tile_wait_all(A); }
+        // one slot: contig set-up on its first tile, the tile itself, and the contig's row-m / reduction epilogue on its last
+        auto process = [&](uint32_t s, const TileRegs& T) __attribute__((always_inline)) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slots[s]);
+            const uint32_t t = (e >> 8) & 0x3FFFFFu;
+            if (e & SLOT_FIRST) {
+                c = e & 0xFFu;
+                wc.JSW = word_make(s_jump[c].score, s_jump[c].len);
+                wc.JSW1 = s_circ[c] ? word_make(rowm_S[c], rowm_len[c] + 1) : wc.JSW;
+                wc.JSW = __builtin_amdgcn_readfirstlane(wc.JSW); wc.JSW1 = __builtin_amdgcn_readfirstlane(wc.JSW1);
+                wc.vrun = __builtin_amdgcn_readfirstlane(s_vrun[c]);
+                wc.m = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_m[c]); wc.roff = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_roff[c]);
+                wc.upS = 0; wc.upT = 0;                                 // row 0 of a Local-mode column: score 0, length 0
+                wc.carry = scan_seed();
+                acc.xw = 0; acc.xrow = 0; acc.ck = 0;
+                rm.F = 0; rm.mv = 0; rm.bits = 0; rm.BD = 0; rm.DG = 0;
+            }
+            PROF(3)
+            if (!(e & SLOT_LAST)) { tile<false>(GP, K, wc, acc, rm, T, lastcol, t, lane, tbcol); PROF(4) return; }
+            tile<true>(GP, K, wc, acc, rm, T, lastcol, t, lane, tbcol);
+            PROF(4)
+            const uint32_t m = wc.m, roff = wc.roff;
             const int owner_lane = (int)(((m - 1) / R) & 63);
-
-            const uint4* __restrict__ stv = reinterpret_cast<const uint4*>(st + 2 * (size_t)roff);
-            uint4 pre[4]; uint2 prex;
-            {
-                const uint32_t o0 = lane * R;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) pre[v] = stv[(o0 >> 1) + v];
-                prex = *reinterpret_cast<const uint2*>(xs + o0);
-            }
-            for (uint32_t t = 0; t + 1 < ntiles; ++t) {
-                uint4 cur[4]; const uint2 curx = prex;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) cur[v] = pre[v];
-                const uint32_t o1 = (t + 1) * TILE + lane * R;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) pre[v] = stv[(o1 >> 1) + v];
-                prex = *reinterpret_cast<const uint2*>(xs + o1);
-                if (j == n) tile<false, true>(V, P, wc, acc, rm, cur, curx, t, lane, st, tbcol);
-                else tile<false, false>(V, P, wc, acc, rm, cur, curx, t, lane, st, tbcol);
-            }
-            if (j == n) tile<true, true>(V, P, wc, acc, rm, pre, prex, ntiles - 1, lane, st, tbcol);
-            else tile<true, false>(V, P, wc, acc, rm, pre, prex, ntiles - 1, lane, st, tbcol);
 
             // ---- wave reductions over rows < m -------------------------------------------------------------------
             // x-suffix running max: max S<<16|len, lowest row among equals; seed (MIN, 0) if there is no row below m
@@ -292,22 +385,22 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
             // ---- row m (:350-351 seeded selection, :406-447 for i == m) -----------------------------------------
             {
                 const uint32_t rmi = roff + m - 1;
-                const int32_t ownS = rm.key >> 3; const uint32_t ownMv = (uint32_t)rm.key & 7u;
+                const int32_t ownS = word_score(rm.F); const uint32_t ownMv = rm.mv, ownSl = word_len(rm.F);
                 int32_t Sm; uint32_t Slm, mvm, lx;
                 lx = xb_.row == 0 ? 0u : m - xb_.row;
                 bool do_x_m = false;
-                if (rowm_run_wins(xb_.v, ownS, rm.dg)) { Sm = xb_.v; Slm = xb_.len; mvm = MK_XSUF; }
-                else { Sm = ownS; Slm = rm.Sl; mvm = ownMv; if (rm.Sl > xb_.len) { do_x_m = true; lx = 0; } }
+                if (rowm_run_wins(xb_.v, ownS, word_score(rm.DG))) { Sm = xb_.v; Slm = xb_.len; mvm = MK_XSUF; }
+                else { Sm = ownS; Slm = ownSl; mvm = ownMv; if (ownSl > xb_.len) { do_x_m = true; lx = 0; } }
                 if (lane == owner_lane) {
-                    st[2 * rmi] = pk16(Sm, Slm); st[2 * rmi + 1] = rm.dpack;
+                    st[2 * rmi] = (uint32_t)word_make(Sm, Slm); st[2 * rmi + 1] = (uint32_t)rm.BD;
                     tbcol[rmi] = (uint8_t)(mvm | rm.bits);
-                    if (j == n) { V.S[rmi] = Sm; V.Slen[rmi] = Slm; }
-                    const uint32_t rl = (j == n) ? (do_x_m ? rm.Sl : xb_.len) : 0u;
+                    if (j == n) { s_cold.S[rmi] = Sm; s_cold.Slen[rmi] = Slm; }
+                    const uint32_t rl = (j == n) ? (do_x_m ? ownSl : xb_.len) : 0u;
                     if (Sm >= wc.vrun) {
-                        const int32_t sn = V.Sn[rmi];
-                        if (Sm > sn || (Sm == sn && Slm > rl)) { V.Sn[rmi] = Sm; V.Ly[rmi] = n - j; V.SnLen[rmi] = Slm; }
+                        const int32_t sn = s_cold.Sn[rmi];
+                        if (Sm > sn || (Sm == sn && Slm > rl)) { s_cold.Sn[rmi] = Sm; s_cold.Ly[rmi] = n - j; s_cold.SnLen[rmi] = Slm; }
                     }
-                    V.Lx[(size_t)c * (n + 1) + j] = lx;
+                    s_cold.Lx[(size_t)c * (n + 1) + j] = lx;
                 }
                 Sm = lane_bcast(Sm, owner_lane); Slm = (uint32_t)lane_bcast((int)Slm, owner_lane); mvm = (uint32_t)lane_bcast((int)mvm, owner_lane);
                 if (lane == 0) {
@@ -319,7 +412,7 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
                     JumpBase b; b.score = cb_.v; b.len = cb_.len + 1; b.from = cb_.row;
                     base[c] = b;
                     if (G > 1) {
-                        unsigned long long* g = xchg + ((size_t)(j & 1) * V.C + c) * 2;
+                        gptr<unsigned long long> g = s_cold.xchg + ((size_t)(j & 1) * C + c) * 2;
                         __hip_atomic_store(g, ((unsigned long long)j << 32) | (uint32_t)b.score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(g + 1, ((unsigned long long)j << 32) | (b.len << 16) | b.from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -327,14 +420,25 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
                     rowm_xsuf[c] = mvm == MK_XSUF; rowm_S[c] = Sm; rowm_len[c] = Slm;
                 }
             }
+            PROF(5)
+        };
+        // two register buffers with fixed roles: while slot s is computed from one, slot s+1 lands in the other
+        for (uint32_t s = sbeg; s < send; s += 2) {
+            { gptr<const u32x4> ps; gptr<const u32x2> px; slot_ptrs(s + 1, ps, px); PROF(3) tile_wait(A); PROF(6) tile_load(B, ps, px); }
+            process(s, A);
+            if (s + 1 >= send) break;
+            { gptr<const u32x4> ps; gptr<const u32x2> px; slot_ptrs(s + 2, ps, px); PROF(3) tile_wait(B); PROF(6) tile_load(A, ps, px); }
+            process(s + 1, B);
         }
+        PROF(3)
         __syncthreads();
+        PROF(7)
         if (G > 1) {
             // gather the other workgroups' records of column j (bounded spin: a missing partner must not hang the GPU)
             for (uint32_t k = threadIdx.x; k < nact; k += blockDim.x) {
                 if (k % G == part) continue;
                 const uint32_t c = s_act[k];
-                const unsigned long long* g = xchg + ((size_t)(j & 1) * V.C + c) * 2;
+                gptr<unsigned long long> g = s_cold.xchg + ((size_t)(j & 1) * C + c) * 2;
                 const unsigned long long t0 = wall_clock64();
                 unsigned long long a, b;
                 for (;;) {
@@ -351,6 +455,9 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
             if (s_abort) { if (threadIdx.x == 0) *V.err = 1; return; }
         }
     }
+#ifdef STITCH_PROFILE
+    if (lane == 0 && blockIdx.x == 0) { unsigned long long* o = (unsigned long long*)(V.err + 4) + wave * 8; for (int k = 0; k < 8; ++k) o[k] = pf_sum[k]; }
+#endif
 }
 
 void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, const FillShared& sh, hipStream_t stream) {

@@ -284,7 +284,7 @@ JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
     L.off_Ival = take(4ull * R); L.off_Ilen = take(4ull * R); L.off_SidxF = take(4ull * R); L.off_SfromF = take(4ull * R);
     L.off_SmoveF = take(R); L.off_ImoveF = take(R);
     L.off_st16 = take(8ull * R);
-    L.off_xchg = take(32ull * c.C + 256);      // 2 parities x C contigs x two 8-byte granules, then the error word
+    L.off_xchg = take(32ull * c.C + 4096);      // 2 parities x C contigs x two 8-byte granules, then the error word
     L.off_tb = take((size_t)L.n * R);
     L.off_Lx = take(4ull * c.C * (L.n + 1)); L.off_jti = take(4ull * c.C * (L.n + 1)); L.off_jtf = take(4ull * c.C * (L.n + 1));
     L.off_Sm = take(4ull * c.C); L.off_Lm = take(4ull * c.C);
@@ -300,6 +300,8 @@ bool local16_ok(const stitch_ctx& c, const Job& jb) {
     if (getenv("STITCH_FORCE_GENERIC")) return false;
     const long long n = (long long)jb.y.size();
     const int32_t lo = std::min({o.mismatch_score, o.gap_open + o.gap_extend, o.jump_same, o.jump_opposite, o.jump_inter, o.match_score});
+    uint32_t tiles = 0; for (uint32_t a : jb.act) tiles += (c.al[a].m + TILE_ROWS - 1) / TILE_ROWS;
+    if (tiles > 4096) return false;                       // the kernel's per-workgroup slot table (fill_local16.hip MAXSLOTS)
     return o.mode == 0 && o.gap_open + o.gap_extend < 0 && (long long)std::max(o.match_score, 0) * n <= 32767 &&
            n + (long long)c.max_m + 2 <= 65535 && lo >= -16000 && o.match_score <= 16000;
 }
@@ -377,7 +379,7 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
             V.S = (int32_t*)(B + L.off_S); V.Slen = (uint32_t*)(B + L.off_Slen); V.D = (int32_t*)(B + L.off_D); V.Dlen = (uint32_t*)(B + L.off_Dlen);
             V.st16 = (uint32_t*)(B + L.off_st16);
             V.xchg = (unsigned long long*)(B + L.off_xchg); V.err = (uint32_t*)(B + L.off_xchg + 32ull * c.C);
-            HIP_TRY(hipMemsetAsync(B + L.off_xchg, 0, 32ull * c.C + 256, c.stream));
+            HIP_TRY(hipMemsetAsync(B + L.off_xchg, 0, 32ull * c.C + 4096, c.stream));
             V.Sn = (int32_t*)(B + L.off_Sn); V.SnLen = (uint32_t*)(B + L.off_SnLen); V.Ly = (uint32_t*)(B + L.off_Ly);
             V.tb = B + L.off_tb; V.Lx = (uint32_t*)(B + L.off_Lx); V.jt_idx = (uint32_t*)(B + L.off_jti); V.jt_from = (uint32_t*)(B + L.off_jtf);
             V.Ival = (int32_t*)(B + L.off_Ival); V.Ilen = (uint32_t*)(B + L.off_Ilen); V.SmoveF = B + L.off_SmoveF;
@@ -426,6 +428,11 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
         HIP_TRY(hipEventElapsedTime(&ms, c.ev[0], c.ev[1])); c.tm.fill_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, c.ev[1], c.ev[2])); c.tm.walk_ms += ms;
         c.tm.launches += 1; c.tm.jobs += nj;
+        if (getenv("STITCH_PROFILE_DUMP") && fast) {
+            unsigned long long pf[64]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[0].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
+            static const char* nm[8] = {"gather/loop", "select", "barrier1", "slot-setup", "tile", "finalize", "tile_wait", "barrier2"};
+            for (int w = 0; w < waves; ++w) { fprintf(stderr, "[prof] wave %d:", w); for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1fM", nm[k], pf[w * 8 + k] / 1e6); fprintf(stderr, "\n"); }
+        }
         if (fast && G > 1) for (uint32_t q = 0; q < nj; ++q) {
             uint32_t e = 0; HIP_TRY(hipMemcpy(&e, views[q].err, 4, hipMemcpyDeviceToHost));
             if (e) return fail(STITCH_EINTERNAL, "a workgroup timed out waiting for its partners (workgroups of one read were not co-resident)");

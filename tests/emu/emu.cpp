@@ -157,19 +157,20 @@ void emu_fill(const EmuCtx& X, EmuJob& J) {
     }
 }
 
-// ---- emulation of fill_local16.hip: key-based selection, 16-bit packed state, 8 rows per lane, filtered Sn ----------
-inline uint32_t pk16(int32_t v, uint32_t len) { return ((uint32_t)v << 16) | (len & 0xFFFFu); }
+// ---- emulation of fill_local16.hip: combined-word selection, 16-bit packed state, 8 rows per lane, filtered Sn ------
 void emu_fill_local(const EmuCtx& X, EmuJob& J) {
     constexpr int R8 = 8; constexpr uint32_t T8 = 64 * R8;
     JobView& V = J.V; const DpParams P = V.P; const uint32_t n = V.n, nact = V.nact, Rtot = V.Rtot;
-    std::vector<uint32_t> st(2 * (size_t)Rtot);
+    std::vector<int32_t> st(2 * (size_t)Rtot);
     std::vector<JumpBase> base(X.C); std::vector<int32_t> vrun(X.C), rowm_S(X.C); std::vector<uint8_t> rowm_mv(X.C); std::vector<uint32_t> rowm_len(X.C);
+    const int32_t GE1 = (int32_t)((uint32_t)P.gap_extend << 16) + 1, GO1 = (int32_t)((uint32_t)(P.gap_open + P.gap_extend) << 16) + 1;
+    const int32_t MW = (int32_t)((uint32_t)P.match << 16), XW = (int32_t)((uint32_t)P.mismatch << 16);
     for (uint32_t k = 0; k < nact; ++k) {
         uint32_t c = V.act[k]; const ContigDesc& cd = V.cd[c];
         uint32_t mpad = (cd.m + PAD - 1) / PAD * PAD;
         for (uint32_t i = 0; i < mpad; ++i) {
             uint32_t r = cd.roff + i, tr = cd.troff + i;
-            st[2 * r] = pk16(X.S0[tr], X.Slen0[tr]); st[2 * r + 1] = pk16(-32768, 0);
+            st[2 * r] = word_make(X.S0[tr], X.Slen0[tr]); st[2 * r + 1] = word_make(-16384, 0);
             V.Sn[r] = X.Sn0[tr]; V.SnLen[r] = X.Slen0[tr]; V.Ly[r] = X.SnSet0[tr] ? n : 0u; V.SmoveF[r] = TB_NONE; V.ImoveF[r] = TB_NONE;
         }
         uint32_t trm = cd.troff + cd.m - 1;
@@ -190,37 +191,33 @@ void emu_fill_local(const EmuCtx& X, EmuJob& J) {
         for (uint32_t k = 0; k < nact; ++k) {
             const uint32_t c = V.act[k]; const ContigDesc cd = V.cd[c]; const uint32_t m = cd.m, roff = cd.roff;
             const uint8_t* xs = V.xseq + cd.seqoff;
-            const int32_t js = sj[c].score; const uint32_t jl = sj[c].len;
-            const int32_t js1 = scirc[c] ? rowm_S[c] : js; const uint32_t jl1 = scirc[c] ? rowm_len[c] + 1 : jl;
+            const int32_t JSW = word_make(sj[c].score, sj[c].len);
+            const int32_t JSW1 = scirc[c] ? word_make(rowm_S[c], rowm_len[c] + 1) : JSW;
             const int32_t vr = vrun[c];
-            int32_t upS = 0, upT = 0; uint32_t upSl = 0, upTl = 0;
+            int32_t upS = 0, upT = 0;                 // words of row 0: score 0, length 0
             ScanEl carry = scan_seed();
             XsRec xb_; xb_.v = MIN_SCORE; xb_.len = 0; xb_.row = 0; CmRec cb_; cb_.v = 0; cb_.row = 0; cb_.len = 0;
-            int32_t ownK = 0, ownDg = 0; uint32_t ownSl = 0, ownBits = 0, ownD = 0;
+            int32_t ownF = 0, ownDG = 0, ownD = 0; uint32_t ownMv = 0, ownBits = 0;
             const uint32_t ntiles = (m + T8 - 1) / T8;
             for (uint32_t t = 0; t < ntiles; ++t) {
-                static int32_t Sp[64][R8], Dp[64][R8]; static uint32_t Slp[64][R8], Dlp[64][R8]; static RowK ra[64][R8]; static ScanEl el[64][R8], agg[64], inc[64], run[64];
-                for (int l = 0; l < 64; ++l) for (int u = 0; u < R8; ++u) {
-                    uint32_t r = roff + t * T8 + l * R8 + u;
-                    Sp[l][u] = (int32_t)(st[2 * r] >> 16); Slp[l][u] = st[2 * r] & 0xFFFFu; Dp[l][u] = (int32_t)(int16_t)(st[2 * r + 1] >> 16); Dlp[l][u] = st[2 * r + 1] & 0xFFFFu;
-                }
+                static int32_t Sp[64][R8], Dp[64][R8]; static RowW ra[64][R8]; static ScanEl el[64][R8], agg[64], inc[64], run[64];
+                for (int l = 0; l < 64; ++l) for (int u = 0; u < R8; ++u) { uint32_t r = roff + t * T8 + l * R8 + u; Sp[l][u] = st[2 * r]; Dp[l][u] = st[2 * r + 1]; }
                 for (int l = 0; l < 64; ++l) for (int u = 0; u < R8; ++u) {
                     uint32_t i = t * T8 + l * R8 + u + 1;
-                    int32_t nS = u ? Sp[l][u - 1] : (l ? Sp[l - 1][R8 - 1] : upS); uint32_t nSl = u ? Slp[l][u - 1] : (l ? Slp[l - 1][R8 - 1] : upSl);
-                    row_phase_a_key(P, xs[i - 1], q, i == 1 ? js1 : js, i == 1 ? jl1 : jl, nS, nSl, Sp[l][u], Slp[l][u], Dp[l][u], Dlp[l][u], ra[l][u]);
+                    int32_t nS = u ? Sp[l][u - 1] : (l ? Sp[l - 1][R8 - 1] : upS);
+                    row_phase_a_word(xs[i - 1] == q ? MW : XW, GE1, GO1, i == 1 ? JSW1 : JSW, nS, Sp[l][u], Dp[l][u], ra[l][u]);
                 }
-                upS = Sp[63][R8 - 1]; upSl = Slp[63][R8 - 1];
+                upS = Sp[63][R8 - 1];
                 for (int l = 0; l < 64; ++l) {
                     for (int u = 0; u < R8; ++u) {
                         uint32_t i = t * T8 + l * R8 + u + 1;
-                        int32_t nT = u ? (ra[l][u - 1].Tk >> 3) : (l ? (ra[l - 1][R8 - 1].Tk >> 3) : upT);
-                        uint32_t nTl = u ? ra[l][u - 1].Tl : (l ? ra[l - 1][R8 - 1].Tl : upTl);
-                        el[l][u] = scan_make(P, i, nT, nTl);
+                        int32_t nT = u ? ra[l][u - 1].T : (l ? ra[l - 1][R8 - 1].T : upT);
+                        el[l][u] = scan_make(P, i, word_score(nT), word_len(nT));
                         if (i > m) el[l][u].key = KEY_NEG_INF;
                     }
                     agg[l] = el[l][0]; for (int u = 1; u < R8; ++u) agg[l] = scan_combine(agg[l], el[l][u]);
                 }
-                upT = ra[63][R8 - 1].Tk >> 3; upTl = ra[63][R8 - 1].Tl;
+                upT = ra[63][R8 - 1].T;
                 inc[0] = agg[0]; for (int l = 1; l < 64; ++l) inc[l] = scan_combine(inc[l - 1], agg[l]);
                 for (int l = 0; l < 64; ++l) run[l] = l == 0 ? carry : scan_combine(carry, inc[l - 1]);
                 carry = scan_combine(carry, inc[63]);
@@ -228,26 +225,27 @@ void emu_fill_local(const EmuCtx& X, EmuJob& J) {
                     uint32_t i = t * T8 + l * R8 + u + 1, r = roff + i - 1; bool valid = i <= m;
                     uint32_t ext = run[l].key >= el[l][u].key ? 1u : 0u; if (!ext) run[l] = el[l][u];
                     int32_t bi = run[l].key + P.gap_extend * (int32_t)i; uint32_t il = (uint32_t)(run[l].q + (int32_t)i);
-                    uint32_t Slo; int32_t fk = row_phase_c_key(ra[l][u], bi, il, Slo); int32_t So = fk >> 3;
-                    uint32_t code = ((uint32_t)fk & 7u) | (ext ? TBB_IEXT : 0u) | (ra[l][u].dext ? TBB_DEXT : 0u);
-                    if (!valid) { st[2 * r] = 0; st[2 * r + 1] = pk16(-32768, 0); continue; }
-                    st[2 * r + 1] = pk16(ra[l][u].bd, ra[l][u].dlen);
+                    uint32_t mv; int32_t F = row_phase_c_word(ra[l][u], bi, il, mv);
+                    int32_t So = word_score(F); uint32_t Slo = word_len(F);
+                    uint32_t code = mv | (ext ? TBB_IEXT : 0u) | (ra[l][u].dext ? TBB_DEXT : 0u);
+                    if (!valid) { st[2 * r] = 0; st[2 * r + 1] = word_make(-16384, 0); continue; }
+                    st[2 * r + 1] = ra[l][u].BD;
                     if (j == n) { V.Ival[r] = bi; V.Ilen[r] = il; }
                     if (i < m) {
-                        st[2 * r] = pk16(So, Slo); tbcol[r] = (uint8_t)code;
+                        st[2 * r] = F; tbcol[r] = (uint8_t)code;
                         if (j == n) { V.S[r] = So; V.Slen[r] = Slo; }
                         XsRec xc; xc.v = So; xc.len = Slo; xc.row = i; if (xs_better(xc, xb_)) xb_ = xc;
                         CmRec cc; cc.v = So; cc.row = i; cc.len = Slo; if (cm_better(cc, cb_)) cb_ = cc;
                         if (So >= vr && Slo > 0u && So >= V.Sn[r]) { V.Sn[r] = So; V.Ly[r] = n - j; V.SnLen[r] = Slo; }
-                    } else { ownK = fk; ownSl = Slo; ownBits = code & (TBB_IEXT | TBB_DEXT); ownDg = ra[l][u].dg; ownD = st[2 * r + 1]; }
+                    } else { ownF = F; ownMv = mv; ownBits = code & (TBB_IEXT | TBB_DEXT); ownDG = ra[l][u].DG; ownD = ra[l][u].BD; }
                 }
             }
             const uint32_t rm = roff + m - 1;
-            int32_t ownS = ownK >> 3; uint32_t ownMv = (uint32_t)ownK & 7u;
+            int32_t ownS = word_score(ownF); uint32_t ownSl = word_len(ownF);
             int32_t Sm; uint32_t Slm, mvm, lx = xb_.row == 0 ? 0u : m - xb_.row; bool do_x_m = false;
-            if (rowm_run_wins(xb_.v, ownS, ownDg)) { Sm = xb_.v; Slm = xb_.len; mvm = MK_XSUF; }
+            if (rowm_run_wins(xb_.v, ownS, word_score(ownDG))) { Sm = xb_.v; Slm = xb_.len; mvm = MK_XSUF; }
             else { Sm = ownS; Slm = ownSl; mvm = ownMv; if (ownSl > xb_.len) { do_x_m = true; lx = 0; } }
-            st[2 * rm] = pk16(Sm, Slm); st[2 * rm + 1] = ownD; tbcol[rm] = (uint8_t)(mvm | ownBits);
+            st[2 * rm] = word_make(Sm, Slm); st[2 * rm + 1] = ownD; tbcol[rm] = (uint8_t)(mvm | ownBits);
             if (j == n) { V.S[rm] = Sm; V.Slen[rm] = Slm; }
             uint32_t rl = (j == n) ? (do_x_m ? ownSl : xb_.len) : 0u;
             if (Sm >= vr) { int32_t sn = V.Sn[rm]; if (Sm > sn || (Sm == sn && Slm > rl)) { V.Sn[rm] = Sm; V.Ly[rm] = n - j; V.SnLen[rm] = Slm; } }
