@@ -63,24 +63,14 @@ def main():
 
     # ---- reference index: built on rank 0, broadcast once over RCCL as a byte blob -----------------------------
     dev = torch.device("cuda", local_rank)
-    if rank == 0:
-        db = synth.make_db(args.contigs, args.contig_len, 1001)
-        index = stitch_amd.Index.from_targets([stitch_amd.TargetSeq(n, s) for n, s in db])
-        blob = index.serialize()
+    from stitch_amd import dist as sdist
+    db = synth.make_db(args.contigs, args.contig_len, 1001)
+    index = stitch_amd.Index.from_targets([stitch_amd.TargetSeq(n, s) for n, s in db]) if rank == 0 else None
     if world > 1:
-        n_blob = torch.tensor([len(blob) if rank == 0 else 0], dtype=torch.int64, device=dev)
-        dist.broadcast(n_blob, src=0)
-        t_blob = torch.empty(int(n_blob.item()), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            t_blob.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
-        dist.broadcast(t_blob, src=0)
-        blob = bytes(t_blob.cpu().numpy().tobytes())
-    index = stitch_amd.Index.deserialize(blob)
+        index = sdist.broadcast_index(index, dist, dev, src=0)          # the one collective: RCCL broadcast of the index blob
     aligners = stitch_amd.Aligners(stitch_amd.Builder().build_options(), index, device=local_rank)
 
     # ---- this rank's shard of the synthetic reads (seed 42 + config id 2; rank-specific stream) ----------------
-    if rank != 0:
-        db = synth.make_db(args.contigs, args.contig_len, 1001)
     R = args.reads_per_step
     total_steps = args.warmup + args.steps
     reads = synth.make_reads(db, R * total_steps, args.read_len, 44 + 1000 * rank)
