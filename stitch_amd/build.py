@@ -25,6 +25,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + \
           [os.path.join(CSRC, f) for f in SOURCES]
+    for d in os.environ.get("STITCH_DEFINES", "").split():
+        cmd.append("-D" + d)                    # experiments only
     if os.environ.get("STITCH_PROFILE_BUILD"):
         cmd.append("-DSTITCH_PROFILE")          # diagnostic build with in-kernel stamps (never shipped)
     if verbose:

@@ -6,14 +6,14 @@
 //   * move selection by ordered integer keys (dp_core.h, row_phase_a_key): the reference's chain of `>` tests
 //     becomes a handful of max operations, and the winning priority is the traceback move code;
 //   * row state is 8 bytes (S<<16 | S.len, D<<16 | D.len) instead of 16, read and written as 16-byte vectors;
-//   * 8 rows per lane (512-row tiles), full tiles run a check-free instance, only a contig's last tile handles
-//     ragged ends and row m;
+//   * 4 rows per lane (256-row tiles; 8 is a build option), 12 waves per workgroup so that three waves share a SIMD;
+//     full tiles run a check-free instance, only a contig's last tile handles ragged ends and row m;
 //   * the next tile's state is prefetched into registers while the current one is computed;
 //   * the insertion scan and the neighbour hand-offs use DPP row shifts / broadcasts instead of LDS permutes;
 //   * the y-suffix trackers Sn/Ly (:431-447) are only touched for cells that reach the contig's running maximum —
 //     in Local mode only rows whose Sn equals the contig's final maximum can influence the result;
-//   * the per-contig jump selection (multi_contig_aligner.rs:292-331) is done once per column by one thread per
-//     contig between two barriers.
+//   * the per-contig jump selection (multi_contig_aligner.rs:292-331) is done by the wave that owns the contig, with
+//     the other contigs' column arg-max spread over its lanes (one barrier per column, two with several workgroups).
 // Eligibility is decided on the host (stitch_api.cpp: local16_ok): mode local, go + ge < 0, match * n <= 32767,
 // n + max contig length < 65535, penalties >= -16000.  Anything else runs the generic int32 kernel.
 #include <hip/hip_runtime.h>
@@ -62,22 +62,39 @@ struct GPtrs {                // hot pointers, kept in registers
 // one; when they are needed the only younger vector-memory operations that must be allowed to stay in flight are the 5
 // stores of the tile computed in between (4 x 16 B state + 8 B traceback), hence vmcnt(5).  Extra (conditional) operations
 // only make the wait stricter.
-struct TileRegs { u32x4 v0, v1, v2, v3; u32x2 x; };
-__device__ __forceinline__ void tile_load(TileRegs& r, gptr<const u32x4> p, gptr<const u32x2> px) {
-    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
-                 : "=&v"(r.v0), "=&v"(r.v1), "=&v"(r.v2), "=&v"(r.v3) : "v"(p) : "memory");
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(r.x) : "v"(px) : "memory");
+#ifndef STITCH_R
+#define STITCH_R 4
+#endif
+constexpr int R = STITCH_R;                    // rows per lane: 8 (512-row tiles) or 4 (256-row tiles, half the registers)
+static_assert(R == 8 || R == 4, "rows per lane");
+struct TileRegs { u32x4 v0, v1, v2, v3; u32x2 x; };      // R == 4 uses v0, v1 and x.x only
+__device__ __forceinline__ void tile_load_plain(TileRegs& r, gptr<const u32x4> p, gptr<const uint8_t> px) {
+    r.v0 = p[0]; r.v1 = p[1];
+    if constexpr (R == 8) { r.v2 = p[2]; r.v3 = p[3]; r.x = *(gptr<const u32x2>)px; } else { r.x.x = *(gptr<const uint32_t>)px; }
 }
+__device__ __forceinline__ void tile_load(TileRegs& r, gptr<const u32x4> p, gptr<const uint8_t> px) {
+    if constexpr (R == 8) {
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                     : "=&v"(r.v0), "=&v"(r.v1), "=&v"(r.v2), "=&v"(r.v3) : "v"(p) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(r.x) : "v"(px) : "memory");
+    } else {
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                     : "=&v"(r.v0), "=&v"(r.v1) : "v"(p) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(r.x.x) : "v"(px) : "memory");
+    }
+}
+// wait until only the stores of the tile computed in between may still be in flight: R/2 state vectors + 1 traceback store
 __device__ __forceinline__ void tile_wait(TileRegs& r) {
-    asm volatile("s_waitcnt vmcnt(5)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.v2), "+v"(r.v3), "+v"(r.x) : : "memory");
+    if constexpr (R == 8) asm volatile("s_waitcnt vmcnt(5)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.v2), "+v"(r.v3), "+v"(r.x) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.x.x) : : "memory");
 }
 __device__ __forceinline__ void tile_wait_all(TileRegs& r) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.v2), "+v"(r.v3), "+v"(r.x) : : "memory");
+    if constexpr (R == 8) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.v2), "+v"(r.v3), "+v"(r.x) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.x.x) : : "memory");
 }
 
 constexpr int MAXC = 256;
-constexpr int R = 8;
 constexpr uint32_t TILE = 64 * R;
 constexpr uint32_t MAXSLOTS = 4096, SLOT_FIRST = 0x40000000u, SLOT_LAST = 0x80000000u;   // slot = contig | tile<<8 | flags
 constexpr int DPP_ROW_SHR0 = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;
@@ -99,6 +116,15 @@ __device__ __forceinline__ void wave_scan(ScanEl& inc) {   // inclusive scan wit
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, d, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), d, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
     return v;
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -137,7 +163,7 @@ struct WordConsts { int32_t MW, XW, GE1, GO1, ge, kb0; };        // match/mismat
 template <bool PARTIAL>
 __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, WaveCol& wc, LaneAcc& acc, RowM& rm, const TileRegs& tr, bool LASTCOL,
                                      uint32_t t, int lane, gptr<uint8_t> tbcol) {
-    const u32x4 cur[4] = {tr.v0, tr.v1, tr.v2, tr.v3}; const u32x2 curx = tr.x;
+    const u32x4 cur[4] = {tr.v0, tr.v1, R == 8 ? tr.v2 : tr.v0, R == 8 ? tr.v3 : tr.v1}; const u32x2 curx = tr.x;
     const uint32_t i0 = t * TILE + lane * R + 1;
     const uint32_t r = wc.roff + i0 - 1;
     const uint32_t m = wc.m;
@@ -218,11 +244,15 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, WaveCo
     }
     gptr<u32x4> stw = (gptr<u32x4>)(V.st + 2 * (size_t)r);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) { u32x4 o; o.x = (uint32_t)Fo[2 * v]; o.y = (uint32_t)ra[2 * v].BD; o.z = (uint32_t)Fo[2 * v + 1]; o.w = (uint32_t)ra[2 * v + 1].BD; stw[v] = o; }
-    u32x2 tbv;
-    tbv.x = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
-    tbv.y = code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24);
-    *(gptr<u32x2>)(tbcol + r) = tbv;
+    for (int v = 0; v < R / 2; ++v) { u32x4 o; o.x = (uint32_t)Fo[2 * v]; o.y = (uint32_t)ra[2 * v].BD; o.z = (uint32_t)Fo[2 * v + 1]; o.w = (uint32_t)ra[2 * v + 1].BD; stw[v] = o; }
+    if constexpr (R == 8) {
+        u32x2 tbv;
+        tbv.x = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+        tbv.y = code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24);
+        *(gptr<u32x2>)(tbcol + r) = tbv;
+    } else {
+        *(gptr<uint32_t>)(tbcol + r) = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+    }
 }
 
 }  // namespace
@@ -231,22 +261,24 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, WaveCo
 // contigs' column arg-max (the next column's jump sources) with the others through 8-byte {data, tag} granules in
 // global memory (agent-scope relaxed atomics: the tag travels with the data, so no fence is needed; double-buffered by
 // column parity).  All G workgroups of a read must be resident at once: the host keeps the grid <= the CU count.
-__global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __restrict__ jobs, FillShared sh, uint32_t G) {
+#ifndef STITCH_LB
+#define STITCH_LB 768          // 12 waves per workgroup: <= 168 VGPRs, 3 waves per SIMD (MAX_WAVES in stitch_api.cpp)
+#endif
+__global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* __restrict__ jobs, FillShared sh, uint32_t G) {
     const JobView& V = jobs[blockIdx.x / G];
     const uint32_t part = blockIdx.x % G;
     const DpParams P = V.P;
     const uint32_t n = V.n, nact = V.nact, Rtot = V.Rtot;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
 
-    __shared__ JumpBase base[MAXC];
-    __shared__ JumpInfo s_jump[MAXC];
-    __shared__ uint8_t s_circ[MAXC];                  // row 1 takes the circular end-to-start jump in this column
+    __shared__ JumpBase base2[2][MAXC];               // column arg-max per contig, double-buffered by column parity:
+                                                      // column j reads [(j-1)&1] while its own results fill [j&1]
     __shared__ uint8_t rowm_xsuf[MAXC];               // cell(m, j-1).S is an x-suffix clip (:263-267)
     __shared__ int32_t rowm_S[MAXC]; __shared__ uint32_t rowm_len[MAXC];
     __shared__ int32_t s_vrun[MAXC];
     __shared__ uint32_t s_act[MAXC]; __shared__ int32_t s_opp[MAXC];
     __shared__ uint32_t s_abort;
-    __shared__ uint32_t s_slots[MAXSLOTS]; __shared__ uint32_t s_wbeg[8], s_wend[8];
+    __shared__ uint32_t s_slots[MAXSLOTS]; __shared__ uint32_t s_wbeg[16], s_wend[16];
     __shared__ uint32_t s_m[MAXC], s_roff[MAXC], s_seq[MAXC];
 
     __shared__ GPtrsCold s_cold;
@@ -259,6 +291,7 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
     GP.st = as_global(V.st16); GP.xseq = as_global(V.xseq); GP.tb = as_global(V.tb); GP.cold = &s_cold;
     const gptr<uint32_t> st = GP.st;
     const uint32_t C = V.C;
+    const int32_t jump_same = P.jump_same, jump_opp = P.jump_opp, jump_inter = P.jump_inter, circular = P.circular;
     WordConsts K;
     K.MW = (int32_t)((uint32_t)P.match << 16); K.XW = (int32_t)((uint32_t)P.mismatch << 16);
     K.GE1 = (int32_t)((uint32_t)P.gap_extend << 16) + 1; K.GO1 = (int32_t)((uint32_t)(P.gap_open + P.gap_extend) << 16) + 1;
@@ -282,7 +315,7 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
         const uint32_t c = V.act[k];
         const uint32_t trm = V.cd[c].troff + V.cd[c].m - 1;
         s_act[k] = c;
-        base[c] = sh.base0[c];
+        base2[0][c] = sh.base0[c];
         s_vrun[c] = sh.base0[c].score;
         rowm_xsuf[c] = sh.Smove0[trm] == TB_XCLIP_SUFFIX; rowm_S[c] = sh.S0[trm]; rowm_len[c] = sh.Slen0[trm];
         if (k % G == part) V.Lx[(size_t)c * (n + 1)] = sh.lx0[c];
@@ -308,33 +341,21 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
     const uint32_t sbeg = s_wbeg[wave], send = s_wend[wave];
 
     // address of slot s's state / bases for this lane (slot index clamped: the pipeline always has a load in flight)
-    auto slot_ptrs = [&](uint32_t s, gptr<const u32x4>& ps, gptr<const u32x2>& px) {
+    auto slot_ptrs = [&](uint32_t s, gptr<const u32x4>& ps, gptr<const uint8_t>& px) {
         s = s < send ? s : send - 1;
         const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slots[s]);
         const uint32_t c = e & 0xFFu, t = (e >> 8) & 0x3FFFFFu;
         const uint32_t roff = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_roff[c]), seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seq[c]);
         const uint32_t o = t * TILE + lane * R;
         ps = (gptr<const u32x4>)(st + 2 * (size_t)(roff + o));
-        px = (gptr<const u32x2>)(GP.xseq + seq + o);
+        px = GP.xseq + seq + o;
     };
 
     PROF_DECL
     for (uint32_t j = 1; j <= n; ++j) {
         PROF(0)
-        // per-contig best jump out of column j-1 (multi_contig_aligner.rs:280-331): one thread per own contig
-        for (uint32_t k = part + threadIdx.x * G; k < nact; k += blockDim.x * G) {
-            const uint32_t c = s_act[k];
-            const JumpInfo ji = select_jump(V.P, base, s_act, nact, c, s_opp[c]);
-            ColCtx cx; cx.jump = ji; cx.circ_ok = (V.P.circular && !rowm_xsuf[c]) ? 1 : 0; cx.circ_score = rowm_S[c]; cx.circ_len = rowm_len[c] + 1;
-            const bool circ = local_row1_circ(cx);
-            s_jump[c] = ji; s_circ[c] = circ ? 1 : 0;
-            s_cold.jt_idx[(size_t)c * (n + 1) + j] = ji.idx | (circ ? JT_CIRC_BIT : 0u);
-            s_cold.jt_from[(size_t)c * (n + 1) + j] = ji.from;
-        }
-        PROF(1)
-        __syncthreads();
-        PROF(2)
-
+        const JumpBase* base = base2[(j - 1) & 1];
+        JumpBase* base_out = base2[j & 1];
         const gptr<uint8_t> tbcol = GP.tb + (size_t)(j - 1) * Rtot;
         // readfirstlane forces the wait for this (compiler-visible) load here, outside the hand-pipelined tile loop
         const uint8_t q = (uint8_t)__builtin_amdgcn_readfirstlane((int)V.y[j - 1]);
@@ -344,15 +365,43 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
         const bool lastcol = (j == n);
         uint32_t c = 0;
         TileRegs A, B;
-        if (sbeg < send) { gptr<const u32x4> ps; gptr<const u32x2> px; slot_ptrs(sbeg, ps, px); tile_load(A, ps, px); tile_wait_all(A); }
+#ifndef STITCH_PLAIN_LOADS
+        if (sbeg < send) { gptr<const u32x4> ps; gptr<const uint8_t> px; slot_ptrs(sbeg, ps, px); tile_load(A, ps, px); tile_wait_all(A); }
+#endif
         // one slot: contig set-up on its first tile, the tile itself, and the contig's row-m / reduction epilogue on its last
         auto process = [&](uint32_t s, const TileRegs& T) __attribute__((always_inline)) {
             const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slots[s]);
             const uint32_t t = (e >> 8) & 0x3FFFFFu;
             if (e & SLOT_FIRST) {
                 c = e & 0xFFu;
-                wc.JSW = word_make(s_jump[c].score, s_jump[c].len);
-                wc.JSW1 = s_circ[c] ? word_make(rowm_S[c], rowm_len[c] + 1) : wc.JSW;
+                // best jump out of column j-1 for contig c (multi_contig_aligner.rs:292-331), computed by this wave: lanes hold
+                // the other contigs' column arg-max; inter-contig = max by (score, len), LAST aligner on full ties (max_by_key)
+                const int32_t opp = s_opp[c];
+                unsigned long long ik = 0;
+                for (uint32_t k = lane; k < nact; k += 64) {
+                    const uint32_t a = s_act[k];
+                    if (a != c && (int32_t)a != opp) {
+                        const JumpBase bb = base[a];
+                        const unsigned long long key = ((unsigned long long)(uint32_t)bb.score << 32) | ((unsigned long long)bb.len << 16) | (k + 1);
+                        ik = key > ik ? key : ik;
+                    }
+                }
+                ik = wave_max_u64(ik);
+                JumpInfo ji; { const JumpBase bs = base[c]; ji.score = bs.score + jump_same; ji.len = bs.len; ji.idx = c; ji.from = bs.from; }
+                if (opp >= 0) { const JumpBase bo = base[opp]; const int32_t sc = bo.score + jump_opp; if (sc > ji.score) { ji.score = sc; ji.len = bo.len; ji.idx = (uint32_t)opp; ji.from = bo.from; } }
+                if (ik != 0) {
+                    const uint32_t a = s_act[(uint32_t)(ik & 0xFFFFu) - 1]; const JumpBase bi_ = base[a];
+                    const int32_t sc = bi_.score + jump_inter;
+                    if (sc > ji.score) { ji.score = sc; ji.len = bi_.len; ji.idx = a; ji.from = bi_.from; }
+                }
+                ColCtx cx; cx.jump = ji; cx.circ_ok = (circular && !rowm_xsuf[c]) ? 1 : 0; cx.circ_score = rowm_S[c]; cx.circ_len = rowm_len[c] + 1;
+                const bool circ = local_row1_circ(cx);
+                if (lane == 0) {
+                    s_cold.jt_idx[(size_t)c * (n + 1) + j] = ji.idx | (circ ? JT_CIRC_BIT : 0u);
+                    s_cold.jt_from[(size_t)c * (n + 1) + j] = ji.from;
+                }
+                wc.JSW = word_make(ji.score, ji.len);
+                wc.JSW1 = circ ? word_make(rowm_S[c], rowm_len[c] + 1) : wc.JSW;
                 wc.JSW = __builtin_amdgcn_readfirstlane(wc.JSW); wc.JSW1 = __builtin_amdgcn_readfirstlane(wc.JSW1);
                 wc.vrun = __builtin_amdgcn_readfirstlane(s_vrun[c]);
                 wc.m = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_m[c]); wc.roff = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_roff[c]);
@@ -410,7 +459,7 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
                         cb_.len = __builtin_nontemporal_load(st + 2 * (size_t)(roff + cb_.row - 1)) & 0xFFFFu;
                     }
                     JumpBase b; b.score = cb_.v; b.len = cb_.len + 1; b.from = cb_.row;
-                    base[c] = b;
+                    base_out[c] = b;
                     if (G > 1) {
                         gptr<unsigned long long> g = s_cold.xchg + ((size_t)(j & 1) * C + c) * 2;
                         __hip_atomic_store(g, ((unsigned long long)j << 32) | (uint32_t)b.score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -422,14 +471,24 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
             }
             PROF(5)
         };
+#ifdef STITCH_PLAIN_LOADS
+        // high-occupancy variant: no hand pipelining; the other waves of the SIMD cover the load latency
+        for (uint32_t s = sbeg; s < send; ++s) {
+            gptr<const u32x4> ps; gptr<const uint8_t> px; slot_ptrs(s, ps, px);
+            tile_load_plain(A, ps, px);
+            PROF(6)
+            process(s, A);
+        }
+#else
         // two register buffers with fixed roles: while slot s is computed from one, slot s+1 lands in the other
         for (uint32_t s = sbeg; s < send; s += 2) {
-            { gptr<const u32x4> ps; gptr<const u32x2> px; slot_ptrs(s + 1, ps, px); PROF(3) tile_wait(A); PROF(6) tile_load(B, ps, px); }
+            { gptr<const u32x4> ps; gptr<const uint8_t> px; slot_ptrs(s + 1, ps, px); PROF(3) tile_wait(A); PROF(6) tile_load(B, ps, px); }
             process(s, A);
             if (s + 1 >= send) break;
-            { gptr<const u32x4> ps; gptr<const u32x2> px; slot_ptrs(s + 2, ps, px); PROF(3) tile_wait(B); PROF(6) tile_load(A, ps, px); }
+            { gptr<const u32x4> ps; gptr<const uint8_t> px; slot_ptrs(s + 2, ps, px); PROF(3) tile_wait(B); PROF(6) tile_load(A, ps, px); }
             process(s + 1, B);
         }
+#endif
         PROF(3)
         __syncthreads();
         PROF(7)
@@ -449,7 +508,7 @@ __global__ __launch_bounds__(512) void fill_local16_kernel(const JobView* __rest
                     __builtin_amdgcn_s_sleep(2);
                 }
                 JumpBase r; r.score = (int32_t)(uint32_t)a; r.len = ((uint32_t)b >> 16) & 0xFFFFu; r.from = (uint32_t)b & 0xFFFFu;
-                base[c] = r;
+                base_out[c] = r;
             }
             __syncthreads();
             if (s_abort) { if (threadIdx.x == 0) *V.err = 1; return; }

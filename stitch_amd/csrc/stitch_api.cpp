@@ -300,15 +300,19 @@ bool local16_ok(const stitch_ctx& c, const Job& jb) {
     if (getenv("STITCH_FORCE_GENERIC")) return false;
     const long long n = (long long)jb.y.size();
     const int32_t lo = std::min({o.mismatch_score, o.gap_open + o.gap_extend, o.jump_same, o.jump_opposite, o.jump_inter, o.match_score});
-    uint32_t tiles = 0; for (uint32_t a : jb.act) tiles += (c.al[a].m + TILE_ROWS - 1) / TILE_ROWS;
+    uint32_t tiles = 0; for (uint32_t a : jb.act) tiles += (c.al[a].m + 255) / 256;      // 256-row tiles when built with 4 rows per lane
     if (tiles > 4096) return false;                       // the kernel's per-workgroup slot table (fill_local16.hip MAXSLOTS)
     return o.mode == 0 && o.gap_open + o.gap_extend < 0 && (long long)std::max(o.match_score, 0) * n <= 32767 &&
            n + (long long)c.max_m + 2 <= 65535 && lo >= -16000 && o.match_score <= 16000;
 }
 
-int pick_waves(uint32_t nact) {                    // fewest rounds of contigs per column, then fewest waves
+constexpr int MAX_WAVES_GENERIC = 8;               // fill_kernel.hip: __launch_bounds__(512)
+constexpr int MAX_WAVES_LOCAL = 12;                // fill_local16.hip: __launch_bounds__(768)
+
+int pick_waves(uint32_t nact, int maxw) {          // fewest rounds of contigs per column, then fewest waves
+    if (const char* e = getenv("STITCH_MAX_WAVES")) maxw = std::max(1, std::min(maxw, atoi(e)));
     int best_w = 1, best_rounds = (int)nact;
-    for (int w = 1; w <= 8; ++w) { int r = ((int)nact + w - 1) / w; if (r < best_rounds) { best_rounds = r; best_w = w; } }
+    for (int w = 1; w <= maxw; ++w) { int r = ((int)nact + w - 1) / w; if (r < best_rounds) { best_rounds = r; best_w = w; } }
     return best_w;
 }
 
@@ -341,7 +345,13 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
         // greedy pack of consecutive jobs into the arena
         size_t k1 = k0, used = 0;
         const size_t view_room = 1 << 20;
-        const size_t max_jobs = fast ? (size_t)c.n_cus : 4096;      // co-residency of the Local-mode kernel's workgroups
+        // Local-mode kernel: every wave should own at most one contig per column (one "round"), so a read is spread over
+        // G >= ceil(contigs / 12) workgroups, and all G workgroups of all reads of a launch must be resident at once.
+        size_t max_jobs = 4096;
+        if (fast) {
+            const uint32_t g_min = std::max(1u, (lay[k0].nact + MAX_WAVES_LOCAL - 1) / MAX_WAVES_LOCAL);
+            max_jobs = std::max<size_t>(1, (size_t)c.n_cus / g_min);
+        }
         while (k1 < jobs.size() && used + lay[k1].bytes + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].bytes; ++k1; }
         if (k1 == k0) return fail(STITCH_ENOMEM, "arena too small for one job");
         const uint32_t nj = (uint32_t)(k1 - k0);
@@ -353,7 +363,7 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
         for (uint32_t q = 0; q < nj; ++q) {
             const Job& jb = jobs[k0 + q]; const JobLayout& L = lay[k0 + q];
             base[q] = o; uint8_t* B = c.arena + o; o += L.bytes;
-            waves = std::max(waves, pick_waves(L.nact));
+            waves = std::max(waves, pick_waves(L.nact, MAX_WAVES_GENERIC));
             // per-job tables
             std::vector<ContigDesc> cd(c.C); std::vector<int32_t> opp(c.C, -1); std::vector<uint8_t> isact(c.C, 0);
             for (uint32_t a : jb.act) isact[a] = 1;
@@ -408,11 +418,11 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
             uint32_t min_act = 0xFFFFFFFFu;
             for (uint32_t q = 0; q < nj; ++q) min_act = std::min(min_act, lay[k0 + q].nact);
             const uint32_t cus = (uint32_t)c.n_cus;
-            G = std::max(1u, std::min({cus / nj, (min_act + 1) / 2, 16u}));
+            G = std::max(1u, std::min({cus / nj, (min_act + 1) / 2, 32u}));
             if (const char* g = getenv("STITCH_WG_PER_READ")) G = std::max(1u, (uint32_t)atoi(g));
             if (nj * G > cus) G = std::max(1u, cus / nj);
             uint32_t max_act = 0; for (uint32_t q = 0; q < nj; ++q) max_act = std::max(max_act, lay[k0 + q].nact);
-            waves = pick_waves((max_act + G - 1) / G);
+            waves = pick_waves((max_act + G - 1) / G, MAX_WAVES_LOCAL);
         }
         c.tm_wg_per_read = G;
         if (fast) launch_fill_local16(d_views, nj, G, waves, sh, c.stream);
