@@ -96,7 +96,7 @@ __device__ __forceinline__ void tile_wait_all(TileRegs& r) {
 
 constexpr int MAXC = 256;
 constexpr uint32_t TILE = 64 * R;
-constexpr uint32_t MAXSLOTS = 4096, SLOT_FIRST = 0x40000000u, SLOT_LAST = 0x80000000u;   // slot = contig | tile<<8 | flags
+constexpr uint32_t MAXSLOTS = 2048, SLOT_FIRST = 0x40000000u, SLOT_LAST = 0x80000000u;   // slot.x = contig | tile<<8 | flags
 constexpr int DPP_ROW_SHR0 = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;
 
 template <int CTRL, int ROW_MASK = 0xF>
@@ -278,7 +278,8 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     __shared__ int32_t s_vrun[MAXC];
     __shared__ uint32_t s_act[MAXC]; __shared__ int32_t s_opp[MAXC];
     __shared__ uint32_t s_abort;
-    __shared__ uint32_t s_slots[MAXSLOTS]; __shared__ uint32_t s_wbeg[16], s_wend[16];
+    __shared__ u32x4 s_slots[MAXSLOTS];               // {contig | tile<<8 | flags, state row of the tile, base offset of the tile, -}
+    __shared__ uint32_t s_wbeg[16], s_wend[16];
     __shared__ uint32_t s_m[MAXC], s_roff[MAXC], s_seq[MAXC];
 
     __shared__ GPtrsCold s_cold;
@@ -331,7 +332,11 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
             for (uint32_t k = part + w * G; k < nact; k += W * G) {
                 const uint32_t c = V.act[k];
                 const uint32_t nt = (V.cd[c].m + TILE - 1) / TILE;
-                for (uint32_t t = 0; t < nt; ++t) if (ns < MAXSLOTS) s_slots[ns++] = c | (t << 8) | (t == 0 ? SLOT_FIRST : 0u) | (t + 1 == nt ? SLOT_LAST : 0u);
+                for (uint32_t t = 0; t < nt; ++t) if (ns < MAXSLOTS) {
+                    u32x4 rec; rec.x = c | (t << 8) | (t == 0 ? SLOT_FIRST : 0u) | (t + 1 == nt ? SLOT_LAST : 0u);
+                    rec.y = V.cd[c].roff + t * TILE; rec.z = V.cd[c].seqoff + t * TILE; rec.w = 0;
+                    s_slots[ns++] = rec;
+                }
             }
             s_wend[w] = ns;
         }
@@ -340,15 +345,12 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     __syncthreads();
     const uint32_t sbeg = s_wbeg[wave], send = s_wend[wave];
 
-    // address of slot s's state / bases for this lane (slot index clamped: the pipeline always has a load in flight)
-    auto slot_ptrs = [&](uint32_t s, gptr<const u32x4>& ps, gptr<const uint8_t>& px) {
-        s = s < send ? s : send - 1;
-        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slots[s]);
-        const uint32_t c = e & 0xFFu, t = (e >> 8) & 0x3FFFFFu;
-        const uint32_t roff = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_roff[c]), seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seq[c]);
-        const uint32_t o = t * TILE + lane * R;
-        ps = (gptr<const u32x4>)(st + 2 * (size_t)(roff + o));
-        px = GP.xseq + seq + o;
+    // slot records are read from LDS one slot ahead of their use, so the LDS latency hides behind a tile's arithmetic
+    auto slot_rec = [&](uint32_t s) -> u32x4 { return s_slots[s < send ? s : send - 1]; };      // clamped: the pipeline always loads
+    auto rec_ptrs = [&](const u32x4& rec, gptr<const u32x4>& ps, gptr<const uint8_t>& px) {
+        const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.y), seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.z);
+        ps = (gptr<const u32x4>)(st + 2 * (size_t)(row + lane * R));
+        px = GP.xseq + seq + lane * R;
     };
 
     PROF_DECL
@@ -366,11 +368,12 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
         uint32_t c = 0;
         TileRegs A, B;
 #ifndef STITCH_PLAIN_LOADS
-        if (sbeg < send) { gptr<const u32x4> ps; gptr<const uint8_t> px; slot_ptrs(sbeg, ps, px); tile_load(A, ps, px); tile_wait_all(A); }
+        u32x4 r0 = slot_rec(sbeg), r1 = slot_rec(sbeg + 1);
+        if (sbeg < send) { gptr<const u32x4> ps; gptr<const uint8_t> px; rec_ptrs(r0, ps, px); tile_load(A, ps, px); tile_wait_all(A); }
 #endif
         // one slot: contig set-up on its first tile, the tile itself, and the contig's row-m / reduction epilogue on its last
-        auto process = [&](uint32_t s, const TileRegs& T) __attribute__((always_inline)) {
-            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slots[s]);
+        auto process = [&](const u32x4& rec, const TileRegs& T) __attribute__((always_inline)) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.x);
             const uint32_t t = (e >> 8) & 0x3FFFFFu;
             if (e & SLOT_FIRST) {
                 c = e & 0xFFu;
@@ -474,19 +477,24 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
 #ifdef STITCH_PLAIN_LOADS
         // high-occupancy variant: no hand pipelining; the other waves of the SIMD cover the load latency
         for (uint32_t s = sbeg; s < send; ++s) {
-            gptr<const u32x4> ps; gptr<const uint8_t> px; slot_ptrs(s, ps, px);
+            const u32x4 rn = slot_rec(s + 1);
+            gptr<const u32x4> ps; gptr<const uint8_t> px; rec_ptrs(r0, ps, px);
             tile_load_plain(A, ps, px);
             PROF(6)
-            process(s, A);
+            process(r0, A);
+            r0 = rn;
         }
 #else
         // two register buffers with fixed roles: while slot s is computed from one, slot s+1 lands in the other
         for (uint32_t s = sbeg; s < send; s += 2) {
-            { gptr<const u32x4> ps; gptr<const uint8_t> px; slot_ptrs(s + 1, ps, px); PROF(3) tile_wait(A); PROF(6) tile_load(B, ps, px); }
-            process(s, A);
+            const u32x4 r2 = slot_rec(s + 2);
+            { gptr<const u32x4> ps; gptr<const uint8_t> px; rec_ptrs(r1, ps, px); PROF(3) tile_wait(A); PROF(6) tile_load(B, ps, px); }
+            process(r0, A);
             if (s + 1 >= send) break;
-            { gptr<const u32x4> ps; gptr<const uint8_t> px; slot_ptrs(s + 2, ps, px); PROF(3) tile_wait(B); PROF(6) tile_load(A, ps, px); }
-            process(s + 1, B);
+            const u32x4 r3 = slot_rec(s + 3);
+            { gptr<const u32x4> ps; gptr<const uint8_t> px; rec_ptrs(r2, ps, px); PROF(3) tile_wait(B); PROF(6) tile_load(A, ps, px); }
+            process(r1, B);
+            r0 = r2; r1 = r3;
         }
 #endif
         PROF(3)

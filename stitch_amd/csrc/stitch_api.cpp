@@ -301,7 +301,7 @@ bool local16_ok(const stitch_ctx& c, const Job& jb) {
     const long long n = (long long)jb.y.size();
     const int32_t lo = std::min({o.mismatch_score, o.gap_open + o.gap_extend, o.jump_same, o.jump_opposite, o.jump_inter, o.match_score});
     uint32_t tiles = 0; for (uint32_t a : jb.act) tiles += (c.al[a].m + 255) / 256;      // 256-row tiles when built with 4 rows per lane
-    if (tiles > 4096) return false;                       // the kernel's per-workgroup slot table (fill_local16.hip MAXSLOTS)
+    if (tiles > 2048u * 16u) return false;                // the kernel's per-workgroup slot table (fill_local16.hip MAXSLOTS) at G <= 16
     return o.mode == 0 && o.gap_open + o.gap_extend < 0 && (long long)std::max(o.match_score, 0) * n <= 32767 &&
            n + (long long)c.max_m + 2 <= 65535 && lo >= -16000 && o.match_score <= 16000;
 }
@@ -349,7 +349,8 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
         // G >= ceil(contigs / 12) workgroups, and all G workgroups of all reads of a launch must be resident at once.
         size_t max_jobs = 4096;
         if (fast) {
-            const uint32_t g_min = std::max(1u, (lay[k0].nact + MAX_WAVES_LOCAL - 1) / MAX_WAVES_LOCAL);
+            uint32_t tiles = 0; for (uint32_t a : jobs[k0].act) tiles += (c.al[a].m + 255) / 256;
+            const uint32_t g_min = std::max({1u, (lay[k0].nact + MAX_WAVES_LOCAL - 1) / MAX_WAVES_LOCAL, (tiles + 1023) / 1024});      // slot table: <= 2048 per workgroup
             max_jobs = std::max<size_t>(1, (size_t)c.n_cus / g_min);
         }
         while (k1 < jobs.size() && used + lay[k1].bytes + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].bytes; ++k1; }
@@ -439,7 +440,7 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
         HIP_TRY(hipEventElapsedTime(&ms, c.ev[1], c.ev[2])); c.tm.walk_ms += ms;
         c.tm.launches += 1; c.tm.jobs += nj;
         if (getenv("STITCH_PROFILE_DUMP") && fast) {
-            unsigned long long pf[64]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[0].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
+            unsigned long long pf[128]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[0].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
             static const char* nm[8] = {"gather/loop", "select", "barrier1", "slot-setup", "tile", "finalize", "tile_wait", "barrier2"};
             for (int w = 0; w < waves; ++w) { fprintf(stderr, "[prof] wave %d:", w); for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1fM", nm[k], pf[w * 8 + k] / 1e6); fprintf(stderr, "\n"); }
         }
