@@ -96,7 +96,11 @@ __device__ __forceinline__ void tile_wait_all(TileRegs& r) {
 
 constexpr int MAXC = 256;
 constexpr uint32_t TILE = 64 * R;
-constexpr uint32_t MAXSLOTS = 2048, SLOT_FIRST = 0x40000000u, SLOT_LAST = 0x80000000u;   // slot.x = contig | tile<<8 | flags
+constexpr uint32_t MAXSLOTS = 2048;
+// slot.x = contig | tile << 8 | flags.  A wave's slots are a contiguous range of the workgroup's (contig, tile) list, so
+// a contig may start in one wave and end in the next: CIN = first slot of a segment that continues another wave's work
+// (wait for its carries in LDS), COUT = last slot of a segment that stops before the contig's last tile (publish them).
+constexpr uint32_t SLOT_FIRST = 0x40000000u, SLOT_LAST = 0x80000000u, SLOT_CIN = 0x20000000u, SLOT_COUT = 0x10000000u, SLOT_TILE_MASK = 0xFFFFFu;
 constexpr int DPP_ROW_SHR0 = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;
 
 template <int CTRL, int ROW_MASK = 0xF>
@@ -278,6 +282,8 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     __shared__ int32_t s_vrun[MAXC];
     __shared__ uint32_t s_act[MAXC]; __shared__ int32_t s_opp[MAXC];
     __shared__ uint32_t s_abort;
+    __shared__ int32_t s_carry[MAXC][12];             // carries handed from the wave that starts a contig to the one that ends it
+    __shared__ uint32_t s_cflag[MAXC];                // (column << 8 | piece) for which s_carry[c] is valid
     __shared__ u32x4 s_slots[MAXSLOTS];               // {contig | tile<<8 | flags, state row of the tile, base offset of the tile, -}
     __shared__ uint32_t s_wbeg[16], s_wend[16];
     __shared__ uint32_t s_m[MAXC], s_roff[MAXC], s_seq[MAXC];
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     K.GE1 = (int32_t)((uint32_t)P.gap_extend << 16) + 1; K.GO1 = (int32_t)((uint32_t)(P.gap_open + P.gap_extend) << 16) + 1;
     K.ge = P.gap_extend; K.kb0 = P.gap_open + P.gap_extend;
     if (threadIdx.x == 0) s_abort = 0;
+    for (uint32_t k = threadIdx.x; k < MAXC; k += blockDim.x) s_cflag[k] = 0;
 
     // ---- column 0 (init_matrices :97-186) ---------------------------------------------------------------------
     for (uint32_t k = part; k < nact; k += G) {
@@ -324,20 +331,54 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     for (uint32_t c = threadIdx.x; c < V.C; c += blockDim.x) s_opp[c] = V.opp_act[c];
     __syncthreads();
 
-    // ---- per-wave slot table: the (contig, tile) pairs this wave walks every column, in order ---------------------
+    // ---- per-wave slot table -------------------------------------------------------------------------------------
+    // The workgroup's tiles (its contigs in order, each top to bottom) are cut into W equal ranges, one per wave, so the
+    // waves are balanced whatever the contig lengths are.  A wave walks, in this order: the head piece of a contig that
+    // continues in the next wave (so that wave is not kept waiting), its whole contigs, and last the piece that continues the
+    // previous wave's contig.
     if (threadIdx.x == 0) {
+        uint32_t NT = 0;
+        for (uint32_t k = part; k < nact; k += G) NT += (V.cd[V.act[k]].m + TILE - 1) / TILE;
+        if (NT > MAXSLOTS) NT = MAXSLOTS;                     // (the host keeps NT within the table)
+        // tile g of the workgroup -> (contig, tile): walk once, emitting records in global order into s_slots[...] scratch order
         uint32_t ns = 0;
         for (int w = 0; w < W; ++w) {
+            const uint32_t lo = (uint32_t)((unsigned long long)NT * w / W), hi = (uint32_t)((unsigned long long)NT * (w + 1) / W);
             s_wbeg[w] = ns;
-            for (uint32_t k = part + w * G; k < nact; k += W * G) {
-                const uint32_t c = V.act[k];
-                const uint32_t nt = (V.cd[c].m + TILE - 1) / TILE;
-                for (uint32_t t = 0; t < nt; ++t) if (ns < MAXSLOTS) {
-                    u32x4 rec; rec.x = c | (t << 8) | (t == 0 ? SLOT_FIRST : 0u) | (t + 1 == nt ? SLOT_LAST : 0u);
-                    rec.y = V.cd[c].roff + t * TILE; rec.z = V.cd[c].seqoff + t * TILE; rec.w = 0;
-                    s_slots[ns++] = rec;
+            // locate (contig, tile) of global tile index `lo`
+            uint32_t g = 0, kk = part, t0 = 0;
+            for (; kk < nact; kk += G) { const uint32_t nt = (V.cd[V.act[kk]].m + TILE - 1) / TILE; if (g + nt > lo) { t0 = lo - g; break; } g += nt; }
+            // first pass: find f = first index in [lo, hi) with tile 0 (or hi if none)
+            uint32_t f = hi;
+            { uint32_t k2 = kk, t = t0; for (uint32_t x = lo; x < hi; ++x) { if (t == 0) { f = x; break; } const uint32_t nt = (V.cd[V.act[k2]].m + TILE - 1) / TILE; if (++t == nt) { t = 0; k2 += G; } } }
+            auto emit = [&](uint32_t from, uint32_t to) {      // records of global tiles [from, to), in order
+                uint32_t k2 = kk, t = t0;
+                for (uint32_t x = lo; x < to; ++x) {
+                    const uint32_t c = V.act[k2]; const uint32_t nt = (V.cd[c].m + TILE - 1) / TILE;
+                    if (x >= from && ns < MAXSLOTS) {
+                        u32x4 rec;
+                        rec.x = c | (t << 8) | (t == 0 ? SLOT_FIRST : 0u) | (t + 1 == nt ? SLOT_LAST : 0u) |
+                                ((x == lo && t != 0) ? SLOT_CIN : 0u) | ((x + 1 == hi && t + 1 != nt) ? SLOT_COUT : 0u);
+                        rec.y = V.cd[c].roff + t * TILE; rec.z = V.cd[c].seqoff + t * TILE;
+                        // piece number of this wave's part of the contig: waves between the one holding tile 0 and this one
+                        const uint32_t gstart = x - t;                                   // global index of the contig's tile 0
+                        uint32_t w0 = (uint32_t)(((unsigned long long)gstart * W) / NT); // candidate wave of gstart, then adjust
+                        while (w0 > 0 && (uint32_t)((unsigned long long)NT * w0 / W) > gstart) --w0;
+                        while ((uint32_t)((unsigned long long)NT * (w0 + 1) / W) <= gstart) ++w0;
+                        rec.w = (uint32_t)w - w0;
+                        s_slots[ns++] = rec;
+                    }
+                    if (++t == nt) { t = 0; k2 += G; }
                 }
-            }
+            };
+            // g = start of the last contig begun in this range if it does not also end here (the piece the NEXT wave waits for)
+            uint32_t gpos = hi;
+            { uint32_t k2 = kk, t = t0, start = lo; bool open_ = (t0 != 0);
+              for (uint32_t x = lo; x < hi; ++x) { if (t == 0) { start = x; open_ = true; } const uint32_t nt = (V.cd[V.act[k2]].m + TILE - 1) / TILE; if (++t == nt) { t = 0; k2 += G; open_ = false; } }
+              if (open_ && start >= f && f < hi) gpos = start; }
+            emit(gpos, hi);     // 1. the head piece the next wave depends on
+            emit(f, gpos);      // 2. whole contigs
+            emit(lo, f);        // 3. the continuation of the previous wave's contig (its head was that wave's step 1)
             s_wend[w] = ns;
         }
     }
@@ -374,7 +415,7 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
         // one slot: contig set-up on its first tile, the tile itself, and the contig's row-m / reduction epilogue on its last
         auto process = [&](const u32x4& rec, const TileRegs& T) __attribute__((always_inline)) {
             const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.x);
-            const uint32_t t = (e >> 8) & 0x3FFFFFu;
+            const uint32_t t = (e >> 8) & SLOT_TILE_MASK;
             if (e & SLOT_FIRST) {
                 c = e & 0xFFu;
                 // best jump out of column j-1 for contig c (multi_contig_aligner.rs:292-331), computed by this wave: lanes hold
@@ -412,9 +453,41 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
                 wc.carry = scan_seed();
                 acc.xw = 0; acc.xrow = 0; acc.ck = 0;
                 rm.F = 0; rm.mv = 0; rm.bits = 0; rm.BD = 0; rm.DG = 0;
+            } else if (e & SLOT_CIN) {
+                // continue a contig another wave started in this column: wait for its carries (same workgroup, always resident)
+                c = e & 0xFFu;
+                const uint32_t want = (j << 8) | ((uint32_t)__builtin_amdgcn_readfirstlane((int)rec.w) & 0xFFu);      // (column, piece)
+                while (__hip_atomic_load(&s_cflag[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
+                wc.upS = __builtin_amdgcn_readfirstlane(s_carry[c][0]); wc.upT = __builtin_amdgcn_readfirstlane(s_carry[c][1]);
+                wc.carry.key = __builtin_amdgcn_readfirstlane(s_carry[c][2]); wc.carry.q = __builtin_amdgcn_readfirstlane(s_carry[c][3]);
+                wc.JSW = __builtin_amdgcn_readfirstlane(s_carry[c][4]); wc.JSW1 = __builtin_amdgcn_readfirstlane(s_carry[c][5]);
+                wc.vrun = __builtin_amdgcn_readfirstlane(s_carry[c][6]);
+                wc.m = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_m[c]); wc.roff = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_roff[c]);
+                // the first wave's records are already reduced; lane 0 carries them on (its rows are the lowest of this piece, and
+                // rows of the earlier piece are lower still, so "lowest row wins" is preserved by the max / min reductions)
+                acc.xw = lane == 0 ? (uint32_t)s_carry[c][7] : 0u; acc.xrow = lane == 0 ? (uint32_t)s_carry[c][8] : 0u;
+                acc.ck = lane == 0 ? (uint32_t)s_carry[c][9] : 0u;
+                rm.F = 0; rm.mv = 0; rm.bits = 0; rm.BD = 0; rm.DG = 0;
             }
             PROF(3)
-            if (!(e & SLOT_LAST)) { tile<false>(GP, K, wc, acc, rm, T, lastcol, t, lane, tbcol); PROF(4) return; }
+            if (!(e & SLOT_LAST)) {
+                tile<false>(GP, K, wc, acc, rm, T, lastcol, t, lane, tbcol);
+                if (e & SLOT_COUT) {
+                    // hand the contig over to the wave that owns its next tile
+                    const uint32_t xw = wave_max_u32(acc.xw);
+                    const uint32_t xrow = wave_min_u32(acc.xw == xw && acc.xrow != 0 ? acc.xrow : 0xFFFFFFFFu);
+                    const uint32_t ck = wave_max_u32(acc.ck);
+                    if (lane == 0) {
+                        s_carry[c][0] = wc.upS; s_carry[c][1] = wc.upT; s_carry[c][2] = wc.carry.key; s_carry[c][3] = wc.carry.q;
+                        s_carry[c][4] = wc.JSW; s_carry[c][5] = wc.JSW1; s_carry[c][6] = wc.vrun;
+                        s_carry[c][7] = (int32_t)xw; s_carry[c][8] = (int32_t)(xrow == 0xFFFFFFFFu ? 0u : xrow); s_carry[c][9] = (int32_t)ck;
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this piece's state words may be re-read by the finishing wave
+                    if (lane == 0) __hip_atomic_store(&s_cflag[c], (j << 8) | (((uint32_t)__builtin_amdgcn_readfirstlane((int)rec.w) + 1u) & 0xFFu), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                PROF(4)
+                return;
+            }
             tile<true>(GP, K, wc, acc, rm, T, lastcol, t, lane, tbcol);
             PROF(4)
             const uint32_t m = wc.m, roff = wc.roff;

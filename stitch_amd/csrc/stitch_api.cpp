@@ -345,12 +345,13 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
         // greedy pack of consecutive jobs into the arena
         size_t k1 = k0, used = 0;
         const size_t view_room = 1 << 20;
-        // Local-mode kernel: every wave should own at most one contig per column (one "round"), so a read is spread over
-        // G >= ceil(contigs / 12) workgroups, and all G workgroups of all reads of a launch must be resident at once.
+        // Local-mode kernel: all G workgroups of all reads of a launch must be resident at once (one workgroup per CU), and a
+        // workgroup's slot table holds 2048 tiles.
         size_t max_jobs = 4096;
+        uint32_t g_min = 1;
         if (fast) {
             uint32_t tiles = 0; for (uint32_t a : jobs[k0].act) tiles += (c.al[a].m + 255) / 256;
-            const uint32_t g_min = std::max({1u, (lay[k0].nact + MAX_WAVES_LOCAL - 1) / MAX_WAVES_LOCAL, (tiles + 1023) / 1024});      // slot table: <= 2048 per workgroup
+            g_min = std::max(1u, (tiles + 2047) / 2048);
             max_jobs = std::max<size_t>(1, (size_t)c.n_cus / g_min);
         }
         while (k1 < jobs.size() && used + lay[k1].bytes + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].bytes; ++k1; }
@@ -419,11 +420,22 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
             uint32_t min_act = 0xFFFFFFFFu;
             for (uint32_t q = 0; q < nj; ++q) min_act = std::min(min_act, lay[k0 + q].nact);
             const uint32_t cus = (uint32_t)c.n_cus;
-            G = std::max(1u, std::min({cus / nj, (min_act + 1) / 2, 32u}));
+            // most workgroups per read that fit, preferring counts that split the contigs evenly (all workgroups of a read
+            // meet every column, so the one with the most contigs sets the pace)
+            const uint32_t g_cap = std::max(1u, std::min({cus / nj, min_act, 32u}));
+            double best = 0;
+            for (uint32_t g = 1; g <= g_cap; ++g) {
+                const double eff = (double)min_act / g / (double)((min_act + g - 1) / g);
+                if (g * eff > best + 1e-9) { best = g * eff; G = g; }
+            }
             if (const char* g = getenv("STITCH_WG_PER_READ")) G = std::max(1u, (uint32_t)atoi(g));
+            G = std::max(G, g_min);
             if (nj * G > cus) G = std::max(1u, cus / nj);
-            uint32_t max_act = 0; for (uint32_t q = 0; q < nj; ++q) max_act = std::max(max_act, lay[k0 + q].nact);
-            waves = pick_waves((max_act + G - 1) / G, MAX_WAVES_LOCAL);
+            // the waves of a workgroup share its tiles evenly (fill_local16.hip), so use all 12 unless there are fewer tiles
+            uint32_t min_tiles = 0xFFFFFFFFu;
+            for (uint32_t q = 0; q < nj; ++q) { uint32_t t = 0; for (uint32_t a : jobs[k0 + q].act) t += (c.al[a].m + 255) / 256; min_tiles = std::min(min_tiles, t / G); }
+            waves = (int)std::max(1u, std::min<uint32_t>(MAX_WAVES_LOCAL, min_tiles));
+            if (const char* e = getenv("STITCH_MAX_WAVES")) waves = std::max(1, std::min(waves, atoi(e)));
         }
         c.tm_wg_per_read = G;
         if (fast) launch_fill_local16(d_views, nj, G, waves, sh, c.stream);
