@@ -134,6 +134,18 @@ def main():
                          "avg_launch_ms": fill_ms / max(1, launches), "walk_kernel_ms_per_step": walk_ms / args.steps,
                          "fill_gcells_per_sec": cells / fill_s / 1e9 if fill_s > 0 else 0.0},
         }
+        # HBM-side traffic of the fill kernel: PMC counters cannot be read from inside this process, so the figure is
+        # the committed rocprofv3 --pmc measurement (profiles/, separate FETCH_SIZE and WRITE_SIZE passes of this same
+        # command, KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) scaled per cell.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_local16.json")))
+            k = pmc["stitch::fill_local16_kernel"]
+            bpc = (2.0 * k["FETCH_SIZE"]["avg_per_launch_raw"] + k["WRITE_SIZE"]["avg_per_launch_raw"]) * 1024.0 / pmc["cells_per_launch"]
+            out["roofline"]["traffic"] = bpc * cells / max(1, launches)
+            out["roofline"]["traffic_source"] = ("profiles/r01_c_pmc_local16.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch of "
+                                                 f"{pmc['cells_per_launch']:.3g} cells = {bpc:.2f} B/cell, scaled to this run's cells per launch")
+        except (OSError, KeyError, ValueError):
+            pass
         if world == 1 and args.cpu_reads > 0:
             from oracle import oracle as orc
             # One 10 kb read is 2.5e9 cells and 40 GB of 16-byte traceback cells for the reference layout (minutes per read
