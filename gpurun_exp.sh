@@ -1,11 +1,4 @@
-set -e
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r01b
-python bench.py > $R/gpurun_out/r01b/bench.json 2> $R/gpurun_out/r01b/bench.err
-tail -c 600 $R/gpurun_out/r01b/bench.json
-cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r01b/kt -o kt -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-reads 0 > $R/gpurun_out/r01b/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r01b/pmc_fetch -o pf -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-reads 0 > $R/gpurun_out/r01b/pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r01b/pmc_write -o pw -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-reads 0 > $R/gpurun_out/r01b/pw.log 2>&1
-find $R/gpurun_out/r01b -type f | head -30
+timeout -k 5 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3
+for r in 64 85; do
+timeout -k 5 120 python bench.py --reads-per-step $r --steps 2 --warmup 1 --cpu-reads 0 2>&1 | grep -i "reads_per" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   reads/s', round(d['value'],2), 'fill_ms', round(d['roofline']['avg_launch_ms'],1), 'walk', round(d['roofline']['walk_kernel_ms_per_step'],1), 'cells/launch', d['roofline']['cells_per_launch'])"
+done

@@ -280,6 +280,7 @@ JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
     L.off_S = take(4ull * R); L.off_Slen = take(4ull * R); L.off_D = take(4ull * R); L.off_Dlen = take(4ull * R);
+    if (L.off_Dlen != L.off_D + 4ull * R) abort();      // fill_local16.hip keeps its 8-byte y-suffix records in D..Dlen
     L.off_Sn = take(4ull * R); L.off_SnLen = take(4ull * R); L.off_Ly = take(4ull * R);
     L.off_Ival = take(4ull * R); L.off_Ilen = take(4ull * R); L.off_SidxF = take(4ull * R); L.off_SfromF = take(4ull * R);
     L.off_SmoveF = take(R); L.off_ImoveF = take(R);
@@ -353,6 +354,7 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
             uint32_t tiles = 0; for (uint32_t a : jobs[k0].act) tiles += (c.al[a].m + 255) / 256;
             g_min = std::max(1u, (tiles + 2047) / 2048);
             max_jobs = std::max<size_t>(1, (size_t)c.n_cus / g_min);
+            if (const char* g = getenv("STITCH_WG_PER_READ")) max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, (uint32_t)std::max(1, atoi(g))));
         }
         while (k1 < jobs.size() && used + lay[k1].bytes + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].bytes; ++k1; }
         if (k1 == k0) return fail(STITCH_ENOMEM, "arena too small for one job");

@@ -5,6 +5,8 @@
 // written as loops over a 64-entry lane array.  It exists so that the column-parallel formulation of the
 // reference's row-serial recurrence can be checked against the oracle in the GPU-less build container
 // (`pytest -m "not gpu"`).  It is not part of the product: libstitch_amd.so does not contain or call it.
+#include <cstdio>
+#include <stdexcept>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -236,7 +238,10 @@ void emu_fill_local(const EmuCtx& X, EmuJob& J) {
                         if (j == n) { V.S[r] = So; V.Slen[r] = Slo; }
                         XsRec xc; xc.v = So; xc.len = Slo; xc.row = i; if (xs_better(xc, xb_)) xb_ = xc;
                         CmRec cc; cc.v = So; cc.row = i; cc.len = Slo; if (cm_better(cc, cb_)) cb_ = cc;
-                        if (So >= vr && Slo > 0u && So >= V.Sn[r]) { V.Sn[r] = So; V.Ly[r] = n - j; V.SnLen[r] = Slo; }
+                        // So >= vr implies So >= Sn[r]: Sn[r] is a maximum over earlier columns of this row and vr the contig's running
+                        // maximum over the same columns, so the kernel stores without reading Sn (checked here)
+                        if (So >= vr && So < V.Sn[r]) throw std::runtime_error("y-suffix tracker invariant: Sn above the contig's running maximum");
+                        if (So >= vr && Slo > 0u) { V.Sn[r] = So; V.Ly[r] = n - j; V.SnLen[r] = Slo; }
                     } else { ownF = F; ownMv = mv; ownBits = code & (TBB_IEXT | TBB_DEXT); ownDG = ra[l][u].DG; ownD = ra[l][u].BD; }
                 }
             }
@@ -248,7 +253,13 @@ void emu_fill_local(const EmuCtx& X, EmuJob& J) {
             st[2 * rm] = word_make(Sm, Slm); st[2 * rm + 1] = ownD; tbcol[rm] = (uint8_t)(mvm | ownBits);
             if (j == n) { V.S[rm] = Sm; V.Slen[rm] = Slm; }
             uint32_t rl = (j == n) ? (do_x_m ? ownSl : xb_.len) : 0u;
-            if (Sm >= vr) { int32_t sn = V.Sn[rm]; if (Sm > sn || (Sm == sn && Slm > rl)) { V.Sn[rm] = Sm; V.Ly[rm] = n - j; V.SnLen[rm] = Slm; } }
+            if (Sm >= vr) {
+                int32_t sn = V.Sn[rm];
+                if (Sm < sn) throw std::runtime_error("y-suffix tracker invariant (row m)");
+                // before the last column rl = 0 and a zero-length S is a clipped 0, which cannot exceed Sn >= 0: the kernel's test is Slm > 0
+                if (j < n && ((Sm > sn || (Sm == sn && Slm > rl)) != (Slm > 0u))) throw std::runtime_error("y-suffix tracker invariant (row m, length)");
+                if (Sm > sn || (Sm == sn && Slm > rl)) { V.Sn[rm] = Sm; V.Ly[rm] = n - j; V.SnLen[rm] = Slm; }
+            }
             V.Lx[(size_t)c * (n + 1) + j] = lx;
             CmRec cc; cc.v = Sm; cc.row = m; cc.len = Slm; if (cm_better(cc, cb_)) cb_ = cc;
             JumpBase b; b.score = cb_.v; b.len = cb_.len + 1; b.from = cb_.row; base[c] = b;
@@ -339,7 +350,8 @@ long emu_job(void* h, const uint8_t* y, uint32_t n, const uint32_t* act, uint32_
     V.SfromF = J.SfromF.data(); V.ImoveF = J.ImoveF.data(); V.Smove0 = X.Smove0.data(); V.Imove0 = X.Imove0.data(); V.Slen0 = X.Slen0.data();
     V.Sm = J.Sm.data(); V.Lm = J.Lm.data();
     V.tb_keyfmt = local16 ? 1u : 0u;
-    if (local16) emu_fill_local(X, J); else emu_fill(X, J);
+    try { if (local16) emu_fill_local(X, J); else emu_fill(X, J); }
+    catch (const std::exception& e) { fprintf(stderr, "emu: %s\n", e.what()); return -3; }
     for (uint32_t k = 0; k < nact; ++k) fixup_contig(V, act[k]);
     uint32_t max_m = 0; for (auto& d : X.cd) max_m = d.m > max_m ? d.m : max_m;
     const uint32_t ops_cap = (n + 1) * (max_m + 2) + 64;   // degenerate scorings (free gaps and jumps) can emit ~n*m ops
