@@ -118,24 +118,31 @@ __device__ __forceinline__ void wave_scan(ScanEl& inc) {   // inclusive scan wit
     scan_step<DPP_ROW_SHR0 | 1>(inc); scan_step<DPP_ROW_SHR0 | 2>(inc); scan_step<DPP_ROW_SHR0 | 4>(inc); scan_step<DPP_ROW_SHR0 | 8>(inc);
     scan_step<DPP_BCAST15, 0xA>(inc); scan_step<DPP_BCAST31, 0xC>(inc);
 }
+// Wave reductions on DPP (VALU rate; a ds_bpermute butterfly is six dependent LDS round trips): the inclusive-scan steps of
+// wave_scan leave the total in lane 63.  Lanes a step does not reach keep `identity`.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false); }
+#ifdef STITCH_BPERM_REDUCE
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o > v ? o : v; }
     return v;
 }
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, d, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), d, 64);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = o > v ? o : v;
-    }
-    return v;
+#else
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    { const uint32_t o = dpp_u32<DPP_ROW_SHR0 | 1>(0u, v); v = o > v ? o : v; } { const uint32_t o = dpp_u32<DPP_ROW_SHR0 | 2>(0u, v); v = o > v ? o : v; }
+    { const uint32_t o = dpp_u32<DPP_ROW_SHR0 | 4>(0u, v); v = o > v ? o : v; } { const uint32_t o = dpp_u32<DPP_ROW_SHR0 | 8>(0u, v); v = o > v ? o : v; }
+    { const uint32_t o = dpp_u32<DPP_BCAST15, 0xA>(0u, v); v = o > v ? o : v; } { const uint32_t o = dpp_u32<DPP_BCAST31, 0xC>(0u, v); v = o > v ? o : v; }
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
-    return v;
+#endif
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
+// max of 64-bit keys hi:lo as two 32-bit reductions: the largest hi, then the largest lo among the lanes that hold it
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t mh = wave_max_u32(hi);
+    const uint32_t ml = wave_max_u32(hi == mh ? lo : 0u);
+    return ((unsigned long long)mh << 32) | ml;
 }
 
 // Rows of a tile are independent, and the scheduler would interleave all eight of them: dozens of compare masks (SGPR
@@ -160,15 +167,29 @@ struct WaveCol {                 // wave-uniform state of one contig's column
 struct LaneAcc {                 // per-lane running records over a contig's column (rows < m)
     uint32_t xw, xrow;           // best S word and its (lowest) row: the x-suffix running max (:406-429)
     uint32_t ck;                 // max of S<<16 | (0xFFFF - row): column arg-max, lowest row (:677-697)
+    uint32_t cklen;              // S.len of the row that holds ck
 };
+// S.len of the column arg-max: the one lane whose record equals the reduced maximum holds it (rows are part of the key)
+__device__ __forceinline__ uint32_t ck_len_of(const LaneAcc& acc, uint32_t ck) {
+    const unsigned long long who = __ballot(acc.ck == ck && ck != 0u);
+    return who ? (uint32_t)__builtin_amdgcn_readlane((int)acc.cklen, (int)__builtin_ctzll(who)) : 0u;
+}
 struct RowM { int32_t F; uint32_t mv, bits; int32_t BD, DG; };   // row m's own selection, finalised after the reduction
 struct WordConsts { int32_t MW, XW, GE1, GO1, ge, kb0; };        // match/mismatch << 16, gap words, ge, go + ge
+// Per-lane constants of the insertion scan.  Keys and lengths are taken relative to the tile (row index within the tile,
+// iL = lane * R + 1 for a lane's first row), so they do not depend on the tile; the wave's carry is rebased by one tile
+// (ge * TILE, TILE) when it moves on.  A tile-relative key lies in (-2^24, 2^23) for every scoring local16_ok admits
+// (|ge| * 256 + 32767 + |go + ge| < 2^23), which leaves the low 6 bits of a word for a lane tag: the wave-level scan is then
+// a plain max (earlier lanes carry the larger tag, so they win ties like the reference's extension, :321) and the winner's
+// length term is fetched from the lane the tag names.
+struct LaneK { int32_t giL; uint32_t iL; int32_t tag; };      // ge * iL, iL, 63 - lane
+constexpr int32_t SCAN_LOW = -(1 << 24);       // below every real tile-relative key: the chain's seed and the padding rows
 
 // One 512-row tile.  PARTIAL: the contig's last tile (rows may exceed m, and row m is held back).  LASTCOL (wave-uniform,
 // run time): j == n, the int32 arrays the fix-up kernel reads are written as well.
 template <bool PARTIAL>
-__device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, WaveCol& wc, LaneAcc& acc, RowM& rm, const TileRegs& tr, bool LASTCOL,
-                                     uint32_t t, int lane, gptr<uint8_t> tbcol) {
+__device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const LaneK& LK, WaveCol& wc, LaneAcc& acc, RowM& rm, TileRegs& tr, bool LASTCOL,
+                                     uint32_t t, int lane, gptr<uint8_t> tbcol, gptr<const u32x4> ps_next, gptr<const uint8_t> px_next) {
     const u32x4 cur[4] = {tr.v0, tr.v1, R == 8 ? tr.v2 : tr.v0, R == 8 ? tr.v3 : tr.v1}; const u32x2 curx = tr.x;
     const uint32_t i0 = t * TILE + lane * R + 1;
     const uint32_t r = wc.roff + i0 - 1;
@@ -189,36 +210,48 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, WaveCo
         row_phase_a_word(xb[u] == wc.q ? K.MW : K.XW, K.GE1, K.GO1, row1 ? wc.JSW1 : wc.JSW, u == 0 ? nS : Sp[u - 1], Sp[u], Dp[u], ra[u]);
         ROW_FENCE
     }
+    // The previous column's words are dead from here on: the NEXT slot's state is loaded into the same registers and lands
+    // during phases B and C (one register buffer; the wait is at the top of the next slot).
+    tile_load(tr, ps_next, px_next);
     // phase B: insertion scan
     const int32_t nT = from_prev_lane(ra[R - 1].T, wc.upT);
     wc.upT = lane_bcast(ra[R - 1].T, 63);
-    const int32_t kb = K.kb0 - K.ge * (int32_t)i0;                                  // key_i = S'(i-1) + go + ge - ge*i
-    const int32_t qb = 1 - (int32_t)i0;                                             // q_i   = S'.len(i-1) + 1 - i
     ScanEl el[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) {
         const int32_t Tup = u == 0 ? nT : ra[u - 1].T;
-        el[u].key = word_score(Tup) + kb - K.ge * u;
-        el[u].q = (int32_t)word_len(Tup) + qb - u;
-        if (PARTIAL && i0 + u > m) el[u].key = KEY_NEG_INF;
+        el[u].key = (word_score(Tup) - LK.giL) + (K.kb0 - K.ge * u);                // key_i = S'(i-1) + go + ge - ge*i   (i within the tile)
+        el[u].q = ((int32_t)word_len(Tup) - (int32_t)LK.iL) + (1 - u);              // q_i   = S'.len(i-1) + 1 - i
+        if (PARTIAL && i0 + u > m) el[u].key = SCAN_LOW;
     }
     ScanEl inc = el[0];
 #pragma unroll
     for (int u = 1; u < R; ++u) inc = scan_combine(inc, el[u]);
-    wave_scan(inc);
-    ScanEl run; run.key = from_prev_lane(inc.key, INT32_MIN); run.q = from_prev_lane(inc.q, 0);
-    run = scan_combine(wc.carry, run);                                              // lane 0: INT32_MIN never wins -> carry
-    { ScanEl last; last.key = lane_bcast(inc.key, 63); last.q = lane_bcast(inc.q, 63); wc.carry = scan_combine(wc.carry, last); }
+    // wave level: max of (key << 6 | 63 - lane); lanes without a source keep INT32_MIN
+    int32_t kt = (int32_t)(((uint32_t)inc.key << 6) | (uint32_t)LK.tag);
+    { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 1>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 2>(INT32_MIN, kt); kt = o > kt ? o : kt; }
+    { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 4>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 8>(INT32_MIN, kt); kt = o > kt ? o : kt; }
+    { const int32_t o = dpp_mov<DPP_BCAST15, 0xA>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_BCAST31, 0xC>(INT32_MIN, kt); kt = o > kt ? o : kt; }
+    ScanEl run;
+    {
+        const int32_t rt = from_prev_lane(kt, INT32_MIN);                           // exclusive: lanes before this one
+        run.key = rt >> 6;                                                          // lane 0: -2^25, below the carry whatever it is
+        run.q = __builtin_amdgcn_ds_bpermute((int)((63u - ((uint32_t)rt & 63u)) << 2), inc.q);
+        run = scan_combine(wc.carry, run);
+        const int32_t lt = lane_bcast(kt, 63);
+        ScanEl last; last.key = lt >> 6; last.q = __builtin_amdgcn_readlane(inc.q, (int)(63u - ((uint32_t)lt & 63u)));
+        wc.carry = scan_combine(wc.carry, last);
+        wc.carry.key += K.ge * (int32_t)TILE; wc.carry.q += (int32_t)TILE;          // relative to the next tile
+    }
     // phase C
-    const int32_t gi0 = K.ge * (int32_t)i0;
     int32_t Fo[R]; uint32_t code[R]; uint32_t tk = 0;
 #pragma unroll
     for (int u = 0; u < R; ++u) {
         const uint32_t i = i0 + u;
         const uint32_t ext = run.key >= el[u].key ? 1u : 0u;
         if (!ext) run = el[u];
-        const int32_t bi = run.key + gi0 + K.ge * u;
-        const uint32_t il = (uint32_t)(run.q + (int32_t)i0 + u);
+        const int32_t bi = run.key + LK.giL + K.ge * u;
+        const uint32_t il = (uint32_t)(run.q + (int32_t)LK.iL + u);
         uint32_t mv;
         const int32_t F = row_phase_c_word(ra[u], bi, il, mv);
         code[u] = mv | (ext ? TBB_IEXT : 0u) | (ra[u].dext ? TBB_DEXT : 0u);
@@ -236,7 +269,15 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, WaveCo
         if (LASTCOL) { if (!PARTIAL || i <= m) { const GPtrsCold& C = *V.cold; C.S[r + u] = word_score(F); C.Slen[r + u] = word_len(F); C.Ival[r + u] = bi; C.Ilen[r + u] = il; } }
         ROW_FENCE
     }
+#ifdef STITCH_CKLEN_MEM
     acc.ck = tk > acc.ck ? tk : acc.ck;
+#else
+    if (tk > acc.ck) {            // a new lane maximum (rare after a contig's first tiles: equal scores keep the lower row)
+        acc.ck = tk;
+#pragma unroll
+        for (int u = 0; u < R; ++u) if ((((uint32_t)Fo[u] & 0xFFFF0000u) | (0xFFFFu - (i0 + u))) == tk) acc.cklen = (uint32_t)Fo[u] & 0xFFFFu;
+    }
+#endif
     // y-suffix trackers (:431-447): only cells that reach the contig's running maximum can matter.  Such a cell
     // has S >= vrun >= Sn (Sn is this row's maximum over earlier columns, vrun the contig's over the same columns; tests/emu
     // checks the invariant), so the reference's test `S > Sn || (S == Sn && len > 0)` is `len > 0`, i.e. the S word > 0, and
@@ -269,6 +310,11 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, WaveCo
 // contigs' column arg-max (the next column's jump sources) with the others through 8-byte {data, tag} granules in
 // global memory (agent-scope relaxed atomics: the tag travels with the data, so no fence is needed; double-buffered by
 // column parity).  All G workgroups of a read must be resident at once: the host keeps the grid <= the CU count.
+#ifndef STITCH_WGT0
+#define STITCH_WGT0 115     // tiles given to a SIMD's first, second and third (or later) wave, relative (measured optimum, flat)
+#define STITCH_WGT1 100
+#define STITCH_WGT2 85
+#endif
 #ifndef STITCH_LB
 #define STITCH_LB 768          // 12 waves per workgroup: <= 168 VGPRs, 3 waves per SIMD (MAX_WAVES in stitch_api.cpp)
 #endif
@@ -290,6 +336,7 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     __shared__ uint32_t s_cflag[MAXC];                // (column << 8 | piece) for which s_carry[c] is valid
     __shared__ u32x4 s_slots[MAXSLOTS];               // {contig | tile<<8 | flags, state row of the tile, base offset of the tile, -}
     __shared__ uint32_t s_wbeg[16], s_wend[16];
+    __shared__ uint32_t s_hwid[16], s_bnd[17];
     __shared__ uint32_t s_m[MAXC], s_roff[MAXC], s_seq[MAXC];
 
     __shared__ GPtrsCold s_cold;
@@ -308,6 +355,8 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     K.MW = (int32_t)((uint32_t)P.match << 16); K.XW = (int32_t)((uint32_t)P.mismatch << 16);
     K.GE1 = (int32_t)((uint32_t)P.gap_extend << 16) + 1; K.GO1 = (int32_t)((uint32_t)(P.gap_open + P.gap_extend) << 16) + 1;
     K.ge = P.gap_extend; K.kb0 = P.gap_open + P.gap_extend;
+    LaneK LK;
+    LK.iL = (uint32_t)lane * R + 1u; LK.giL = K.ge * (int32_t)LK.iL; LK.tag = 63 - lane;
     if (threadIdx.x == 0) s_abort = 0;
     for (uint32_t k = threadIdx.x; k < MAXC; k += blockDim.x) s_cflag[k] = 0;
 
@@ -341,14 +390,27 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     // waves are balanced whatever the contig lengths are.  A wave walks, in this order: the head piece of a contig that
     // continues in the next wave (so that wave is not kept waiting), its whole contigs, and last the piece that continues the
     // previous wave's contig.
+    // The SIMD serves its waves strictly in wave-slot order (s_setprio does not change it: measured), so of the three waves
+    // a SIMD holds, the one in the lowest slot needs 0.6x and the one in the highest 1.0x of the time for the same tiles.
+    // The tile ranges are therefore cut in proportion to a weight by a wave's rank among the waves of its SIMD.
+    if (lane == 0) s_hwid[wave] = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID: wave slot [3:0], SIMD [5:4]
+    __syncthreads();
     if (threadIdx.x == 0) {
+        uint32_t wsum = 0;
+        for (int w = 0; w < W; ++w) {
+            uint32_t rank = 0;
+            for (int v = 0; v < W; ++v) if (((s_hwid[v] >> 4) & 3u) == ((s_hwid[w] >> 4) & 3u) && (s_hwid[v] & 15u) < (s_hwid[w] & 15u)) ++rank;
+            s_bnd[w] = wsum;
+            wsum += rank == 0 ? STITCH_WGT0 : rank == 1 ? STITCH_WGT1 : STITCH_WGT2;
+        }
+        s_bnd[W] = wsum;
         uint32_t NT = 0;
         for (uint32_t k = part; k < nact; k += G) NT += (V.cd[V.act[k]].m + TILE - 1) / TILE;
         if (NT > MAXSLOTS) NT = MAXSLOTS;                     // (the host keeps NT within the table)
         // tile g of the workgroup -> (contig, tile): walk once, emitting records in global order into s_slots[...] scratch order
         uint32_t ns = 0;
         for (int w = 0; w < W; ++w) {
-            const uint32_t lo = (uint32_t)((unsigned long long)NT * w / W), hi = (uint32_t)((unsigned long long)NT * (w + 1) / W);
+            const uint32_t lo = (uint32_t)((unsigned long long)NT * s_bnd[w] / wsum), hi = (uint32_t)((unsigned long long)NT * s_bnd[w + 1] / wsum);
             s_wbeg[w] = ns;
             // locate (contig, tile) of global tile index `lo`
             uint32_t g = 0, kk = part, t0 = 0;
@@ -367,9 +429,8 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
                         rec.y = V.cd[c].roff + t * TILE; rec.z = V.cd[c].seqoff + t * TILE;
                         // piece number of this wave's part of the contig: waves between the one holding tile 0 and this one
                         const uint32_t gstart = x - t;                                   // global index of the contig's tile 0
-                        uint32_t w0 = (uint32_t)(((unsigned long long)gstart * W) / NT); // candidate wave of gstart, then adjust
-                        while (w0 > 0 && (uint32_t)((unsigned long long)NT * w0 / W) > gstart) --w0;
-                        while ((uint32_t)((unsigned long long)NT * (w0 + 1) / W) <= gstart) ++w0;
+                        uint32_t w0 = (uint32_t)w;                                       // the wave whose range holds gstart
+                        while (w0 > 0 && (uint32_t)((unsigned long long)NT * s_bnd[w0] / wsum) > gstart) --w0;
                         rec.w = (uint32_t)w - w0;
                         s_slots[ns++] = rec;
                     }
@@ -400,26 +461,29 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     };
 
     PROF_DECL
+    uint32_t ychunk = 0;
     for (uint32_t j = 1; j <= n; ++j) {
         PROF(0)
         const JumpBase* base = base2[(j - 1) & 1];
         JumpBase* base_out = base2[j & 1];
         const gptr<uint8_t> tbcol = GP.tb + (size_t)(j - 1) * Rtot;
-        // readfirstlane forces the wait for this (compiler-visible) load here, outside the hand-pipelined tile loop
+        // the read's bases, 64 columns per (coalesced) load: lane l holds y[jb + l]
+#ifdef STITCH_Y_DIRECT
         const uint8_t q = (uint8_t)__builtin_amdgcn_readfirstlane((int)V.y[j - 1]);
+#else
+        if (((j - 1) & 63u) == 0) ychunk = (j - 1 + lane < n) ? (uint32_t)V.y[j - 1 + lane] : 0u;
+        const uint8_t q = (uint8_t)__builtin_amdgcn_readlane((int)ychunk, (int)((j - 1) & 63u));
+#endif
 
         WaveCol wc; LaneAcc acc; RowM rm;
         wc.j = j; wc.n = n; wc.q = (uint32_t)q;
         const bool lastcol = (j == n);
         uint32_t c = 0;
-        TileRegs A, B;
-#ifndef STITCH_PLAIN_LOADS
-        u32x4 r0 = slot_rec(sbeg), r1 = slot_rec(sbeg + 1);
-        if (sbeg < send) { gptr<const u32x4> ps; gptr<const uint8_t> px; rec_ptrs(r0, ps, px); tile_load(A, ps, px); tile_wait_all(A); }
-#endif
+        TileRegs T;
+        u32x4 rn = slot_rec(sbeg);
+        if (sbeg < send) { gptr<const u32x4> ps; gptr<const uint8_t> px; rec_ptrs(rn, ps, px); tile_load(T, ps, px); }
         // one slot: contig set-up on its first tile, the tile itself, and the contig's row-m / reduction epilogue on its last
-        auto process = [&](const u32x4& rec, const TileRegs& T) __attribute__((always_inline)) {
-            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.x);
+        auto process = [&](uint32_t e, uint32_t piece, TileRegs& T, gptr<const u32x4> psn, gptr<const uint8_t> pxn) __attribute__((always_inline)) {
             const uint32_t t = (e >> 8) & SLOT_TILE_MASK;
             if (e & SLOT_FIRST) {
                 c = e & 0xFFu;
@@ -455,13 +519,13 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
                 wc.vrun = __builtin_amdgcn_readfirstlane(s_vrun[c]); wc.thr = wc.vrun > 0 ? (int32_t)((uint32_t)wc.vrun << 16) : 1;
                 wc.m = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_m[c]); wc.roff = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_roff[c]);
                 wc.upS = 0; wc.upT = 0;                                 // row 0 of a Local-mode column: score 0, length 0
-                wc.carry = scan_seed();
-                acc.xw = 0; acc.xrow = 0; acc.ck = 0;
+                wc.carry.key = SCAN_LOW; wc.carry.q = 0;
+                acc.xw = 0; acc.xrow = 0; acc.ck = 0; acc.cklen = 0;
                 rm.F = 0; rm.mv = 0; rm.bits = 0; rm.BD = 0; rm.DG = 0;
             } else if (e & SLOT_CIN) {
                 // continue a contig another wave started in this column: wait for its carries (same workgroup, always resident)
                 c = e & 0xFFu;
-                const uint32_t want = (j << 8) | ((uint32_t)__builtin_amdgcn_readfirstlane((int)rec.w) & 0xFFu);      // (column, piece)
+                const uint32_t want = (j << 8) | (piece & 0xFFu);      // (column, piece)
                 while (__hip_atomic_load(&s_cflag[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
                 wc.upS = __builtin_amdgcn_readfirstlane(s_carry[c][0]); wc.upT = __builtin_amdgcn_readfirstlane(s_carry[c][1]);
                 wc.carry.key = __builtin_amdgcn_readfirstlane(s_carry[c][2]); wc.carry.q = __builtin_amdgcn_readfirstlane(s_carry[c][3]);
@@ -471,29 +535,29 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
                 // the first wave's records are already reduced; lane 0 carries them on (its rows are the lowest of this piece, and
                 // rows of the earlier piece are lower still, so "lowest row wins" is preserved by the max / min reductions)
                 acc.xw = lane == 0 ? (uint32_t)s_carry[c][7] : 0u; acc.xrow = lane == 0 ? (uint32_t)s_carry[c][8] : 0u;
-                acc.ck = lane == 0 ? (uint32_t)s_carry[c][9] : 0u;
+                acc.ck = lane == 0 ? (uint32_t)s_carry[c][9] : 0u; acc.cklen = lane == 0 ? (uint32_t)s_carry[c][10] : 0u;
                 rm.F = 0; rm.mv = 0; rm.bits = 0; rm.BD = 0; rm.DG = 0;
             }
             PROF(3)
             if (!(e & SLOT_LAST)) {
-                tile<false>(GP, K, wc, acc, rm, T, lastcol, t, lane, tbcol);
+                tile<false>(GP, K, LK, wc, acc, rm, T, lastcol, t, lane, tbcol, psn, pxn);
                 if (e & SLOT_COUT) {
                     // hand the contig over to the wave that owns its next tile
                     const uint32_t xw = wave_max_u32(acc.xw);
                     const uint32_t xrow = wave_min_u32(acc.xw == xw && acc.xrow != 0 ? acc.xrow : 0xFFFFFFFFu);
                     const uint32_t ck = wave_max_u32(acc.ck);
+                    const uint32_t cklen = ck_len_of(acc, ck);
                     if (lane == 0) {
                         s_carry[c][0] = wc.upS; s_carry[c][1] = wc.upT; s_carry[c][2] = wc.carry.key; s_carry[c][3] = wc.carry.q;
                         s_carry[c][4] = wc.JSW; s_carry[c][5] = wc.JSW1; s_carry[c][6] = wc.vrun;
-                        s_carry[c][7] = (int32_t)xw; s_carry[c][8] = (int32_t)(xrow == 0xFFFFFFFFu ? 0u : xrow); s_carry[c][9] = (int32_t)ck;
+                        s_carry[c][7] = (int32_t)xw; s_carry[c][8] = (int32_t)(xrow == 0xFFFFFFFFu ? 0u : xrow); s_carry[c][9] = (int32_t)ck; s_carry[c][10] = (int32_t)cklen;
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this piece's state words may be re-read by the finishing wave
-                    if (lane == 0) __hip_atomic_store(&s_cflag[c], (j << 8) | (((uint32_t)__builtin_amdgcn_readfirstlane((int)rec.w) + 1u) & 0xFFu), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (lane == 0) __hip_atomic_store(&s_cflag[c], (j << 8) | ((piece + 1u) & 0xFFu), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 PROF(4)
                 return;
             }
-            tile<true>(GP, K, wc, acc, rm, T, lastcol, t, lane, tbcol);
+            tile<true>(GP, K, LK, wc, acc, rm, T, lastcol, t, lane, tbcol, psn, pxn);
             PROF(4)
             const uint32_t m = wc.m, roff = wc.roff;
             const int owner_lane = (int)(((m - 1) / R) & 63);
@@ -510,8 +574,10 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
             }
             else { xb_.v = (int32_t)(xw >> 16); xb_.len = xw & 0xFFFFu; xb_.row = xrow; }
             // column arg-max over rows 0..m-1: row 0 holds S = 0 (key 0xFFFF); the winner's length is re-read from the state
-            uint32_t ck = wave_max_u32(acc.ck); ck = ck > 0xFFFFu ? ck : 0xFFFFu;
-            CmRec cb_; cb_.v = (int32_t)(ck >> 16); cb_.row = 0xFFFFu - (ck & 0xFFFFu); cb_.len = 0;
+            uint32_t ck = wave_max_u32(acc.ck);
+            const uint32_t cklen = ck_len_of(acc, ck);
+            ck = ck > 0xFFFFu ? ck : 0xFFFFu;
+            CmRec cb_; cb_.v = (int32_t)(ck >> 16); cb_.row = 0xFFFFu - (ck & 0xFFFFu); cb_.len = cb_.row != 0 ? cklen : 0u;
             // ---- row m (:350-351 seeded selection, :406-447 for i == m) -----------------------------------------
             {
                 const uint32_t rmi = roff + m - 1;
@@ -538,10 +604,12 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
                 Sm = lane_bcast(Sm, owner_lane); Slm = (uint32_t)lane_bcast((int)Slm, owner_lane); mvm = (uint32_t)lane_bcast((int)mvm, owner_lane);
                 if (lane == 0) {
                     if (Sm > cb_.v) { cb_.v = Sm; cb_.row = m; cb_.len = Slm; }
+#ifdef STITCH_CKLEN_MEM
                     else if (cb_.row != 0) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the winner's state word was stored by this wave above
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         cb_.len = __builtin_nontemporal_load(st + 2 * (size_t)(roff + cb_.row - 1)) & 0xFFFFu;
                     }
+#endif
                     JumpBase b; b.score = cb_.v; b.len = cb_.len + 1; b.from = cb_.row;
                     base_out[c] = b;
                     if (G > 1) {
@@ -555,29 +623,16 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
             }
             PROF(5)
         };
-#ifdef STITCH_PLAIN_LOADS
-        // high-occupancy variant: no hand pipelining; the other waves of the SIMD cover the load latency
+        // one register buffer: slot s+1's state is loaded inside slot s's tile, after its last use of the registers
         for (uint32_t s = sbeg; s < send; ++s) {
-            const u32x4 rn = slot_rec(s + 1);
-            gptr<const u32x4> ps; gptr<const uint8_t> px; rec_ptrs(r0, ps, px);
-            tile_load_plain(A, ps, px);
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)rn.x), piece = (uint32_t)__builtin_amdgcn_readfirstlane((int)rn.w);
+            rn = slot_rec(s + 1);                                   // LDS read, used after phase A (clamped: the last slot reloads itself)
+            PROF(3)
+            if (s == sbeg) tile_wait_all(T); else tile_wait(T);
             PROF(6)
-            process(r0, A);
-            r0 = rn;
+            gptr<const u32x4> psn; gptr<const uint8_t> pxn; rec_ptrs(rn, psn, pxn);
+            process(e, piece, T, psn, pxn);
         }
-#else
-        // two register buffers with fixed roles: while slot s is computed from one, slot s+1 lands in the other
-        for (uint32_t s = sbeg; s < send; s += 2) {
-            const u32x4 r2 = slot_rec(s + 2);
-            { gptr<const u32x4> ps; gptr<const uint8_t> px; rec_ptrs(r1, ps, px); PROF(3) tile_wait(A); PROF(6) tile_load(B, ps, px); }
-            process(r0, A);
-            if (s + 1 >= send) break;
-            const u32x4 r3 = slot_rec(s + 3);
-            { gptr<const u32x4> ps; gptr<const uint8_t> px; rec_ptrs(r2, ps, px); PROF(3) tile_wait(B); PROF(6) tile_load(A, ps, px); }
-            process(r1, B);
-            r0 = r2; r1 = r3;
-        }
-#endif
         PROF(3)
         __syncthreads();
         PROF(7)
@@ -614,6 +669,7 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
         }
     }
 #ifdef STITCH_PROFILE
+    pf_sum[1] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8]
     if (lane == 0 && blockIdx.x == 0) { unsigned long long* o = (unsigned long long*)(V.err + 4) + wave * 8; for (int k = 0; k < 8; ++k) o[k] = pf_sum[k]; }
 #endif
 }
