@@ -246,6 +246,36 @@ void launch_fill(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillSh
 // fix-up of one contig each (single_contig_aligner.rs:453-555), then lanes walk (traceback/mod.rs:219-373).
 // mode: 0 = traceback (best end contig), 1 = one chain per active contig (traceback_all candidates, chosen among
 // on the host in the reference's order), 2 = traceback_from(from).
+// One wavefront, one walk: every lane carries the same state (walk_core.h, walk_from_t), lane 0 writes.
+struct WaveWalk {
+    int lane;
+    __device__ bool writer() const { return lane == 0; }
+    // Cells (i-l, j-l), l = 0..63, fetched by lane l.  Returns the number L of leading cells that are plain diagonal steps
+    // (traceback code MV_DIAG: source = the cell up-left in the same contig) with row >= 2 and 1 <= column < n (row 1 can
+    // hold the circular jump, column n the fix-up overrides: both stay on the literal path); their operations are written
+    // by the lanes themselves.
+    __device__ uint32_t diag_run(const JobView& V, uint32_t cur, uint32_t i, uint32_t j, uint32_t nops, OpRec* ops, uint32_t ops_cap) const {
+        const uint32_t l = (uint32_t)lane;
+        const bool inb = l + 2 <= i && l + 1 <= j && j - l < V.n;
+        bool ok = false, match = false;
+        if (inb) {
+            const ContigDesc d = V.cd[cur];
+            const uint32_t ii = i - l, jj = j - l;
+            const uint32_t raw = V.tb[(size_t)(jj - 1) * V.Rtot + d.roff + ii - 1];
+            const uint32_t code = V.tb_keyfmt ? key_code_to_generic(raw, false) : raw;
+            ok = (code & 7u) == MV_DIAG;
+            match = V.xseq[d.seqoff + ii - 1] == V.y[jj - 1];
+        }
+        const unsigned long long bad = ~__ballot(ok);
+        const uint32_t L = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+        if (l < L && nops + l < ops_cap) { OpRec o; o.kind = match ? OP_MATCH : OP_SUBST; o.pad = 0; o.contig = 0; o.arg = 0; ops[nops + l] = o; }
+        return L;
+    }
+    __device__ void reverse(OpRec* ops, uint32_t nops) const {
+        for (uint32_t a = (uint32_t)lane; a < nops / 2; a += 64) { const OpRec t = ops[a]; ops[a] = ops[nops - 1 - a]; ops[nops - 1 - a] = t; }
+    }
+};
+
 __global__ __launch_bounds__(64) void fixup_walk_kernel(const JobView* __restrict__ jobs, const WalkArgs* __restrict__ args) {
     const JobView& V = jobs[blockIdx.x];
     const WalkArgs A = args[blockIdx.x];
@@ -254,9 +284,12 @@ __global__ __launch_bounds__(64) void fixup_walk_kernel(const JobView* __restric
     __syncthreads();
     if (A.mode == 1) {
         for (uint32_t k = lane; k < V.nact; k += 64) walk_from(V, V.act[k], A.hdr[k], A.ops + (size_t)k * A.ops_cap, A.ops_cap);
-    } else if (lane == 0) {
-        uint32_t c = A.mode == 0 ? pick_primary(V) : A.from;
-        walk_from(V, c, A.hdr[0], A.ops, A.ops_cap);
+    } else {
+        const uint32_t c = A.mode == 0 ? pick_primary(V) : A.from;
+        ChainHdr H;
+        WaveWalk ex; ex.lane = lane;
+        walk_from_t(V, c, H, A.ops, A.ops_cap, ex);
+        if (lane == 0) A.hdr[0] = H;
     }
 }
 

@@ -214,8 +214,18 @@ STITCH_HD bool is_active(const JobView& V, uint32_t c) {
     return false;
 }
 
+// How a walk is executed.  SoloWalk: one thread, literal.  On the GPU a whole wavefront can run ONE walk with identical
+// state in every lane (fill_kernel.hip, WaveWalk): lane 0 does the writes, and on a run of plain diagonal steps the 64 lanes
+// fetch 64 cells of the diagonal at once, so the walk pays one memory latency per run instead of one per cell.
+struct SoloWalk {
+    STITCH_HD bool writer() const { return true; }
+    STITCH_HD uint32_t diag_run(const JobView&, uint32_t, uint32_t, uint32_t, uint32_t, OpRec*, uint32_t) const { return 0; }
+    STITCH_HD void reverse(OpRec* ops, uint32_t nops) const { for (uint32_t a = 0, b = nops; a + 1 < b; ++a, --b) { OpRec t = ops[a]; ops[a] = ops[b - 1]; ops[b - 1] = t; } }
+};
+
 // traceback_from (align/traceback/mod.rs:219-373).  Ops are written in reverse and flipped at the end.
-STITCH_HD void walk_from(const JobView& V, uint32_t contig_index, ChainHdr& H, OpRec* ops, uint32_t ops_cap) {
+template <typename Exec>
+STITCH_HD void walk_from_t(const JobView& V, uint32_t contig_index, ChainHdr& H, OpRec* ops, uint32_t ops_cap, const Exec& ex) {
     const uint32_t n = V.n;
     H.status = 0; H.n_ops = 0; H.end_contig_idx = contig_index;
     if (contig_index >= V.C || !is_active(V, contig_index)) { H.status = 1; return; }
@@ -232,16 +242,28 @@ STITCH_HD void walk_from(const JobView& V, uint32_t contig_index, ChainHdr& H, O
     if (max_steps > 50000000ull) max_steps = 50000000ull;                           // a runaway walk must end in seconds, not hours
     uint64_t steps = 0;
     auto push = [&](uint8_t kind, uint32_t contig, uint32_t arg) {
-        if (nops < ops_cap) { OpRec o; o.kind = kind; o.pad = 0; o.contig = (uint16_t)contig; o.arg = arg; ops[nops] = o; }
+        if (nops < ops_cap) { if (ex.writer()) { OpRec o; o.kind = kind; o.pad = 0; o.contig = (uint16_t)contig; o.arg = arg; ops[nops] = o; } }
         else H.status = 2;
         if (nops == 0) first_kind = kind;
         ++nops;
     };
     for (;;) {
         if (++steps > max_steps) { H.status = 3; break; }
-        if (!is_active(V, cur)) { H.status = 1; return; }
+        // (cur is checked against the active set where it changes: at the start and after every jump)
         uint32_t next_layer;
         if (last_layer == TB_START) break;
+        if (last_layer == TB_MATCH || last_layer == TB_SUBST) {
+            // a run of L cells (i,j), (i-1,j-1), ... that are all plain diagonal steps inside the matrix (row >= 2, column < n):
+            // exactly what L turns of the branch below would do, without a jump in between
+            const uint32_t L = ex.diag_run(V, cur, i, j, nops, ops, ops_cap);
+            if (L) {
+                if (nops == 0) first_kind = last_layer == TB_MATCH ? OP_MATCH : OP_SUBST;
+                if (nops + L > ops_cap) H.status = 2;
+                nops += L; steps += L; i -= L; j -= L;
+                last_layer = s_move(V, cur, i, j);
+                continue;
+            }
+        }
         if (last_layer == TB_INS) {
             push(OP_INS, 0, 0);
             next_layer = i_move(V, cur, i, j);
@@ -298,12 +320,13 @@ STITCH_HD void walk_from(const JobView& V, uint32_t contig_index, ChainHdr& H, O
         last_layer = next_layer;
     }
     if (H.status == 2) { H.n_ops = nops; return; }
-    for (uint32_t a = 0, b = nops; a + 1 < b; ++a, --b) { OpRec t = ops[a]; ops[a] = ops[b - 1]; ops[b - 1] = t; }
+    ex.reverse(ops, nops);
     bool all_special = true;
     for (uint32_t k = 0; k < nops; ++k) { uint8_t kd = ops[k].kind; if (!(kd == OP_XCLIP || kd == OP_YCLIP || kd == OP_XJUMP)) { all_special = false; break; } }
     if (all_special) { xstart = 0; xend = 0; ystart = 0; yend = 0; }
     H.score = score; H.xstart = xstart; H.xend = xend; H.ystart = ystart; H.yend = yend; H.xlen = xlen; H.ylen = n;
     H.start_contig_idx = cur; H.end_contig_idx = contig_index; H.length = alignment_length; H.n_ops = nops;
 }
+STITCH_HD void walk_from(const JobView& V, uint32_t contig_index, ChainHdr& H, OpRec* ops, uint32_t ops_cap) { walk_from_t(V, contig_index, H, ops, ops_cap, SoloWalk()); }
 
 }  // namespace stitch
