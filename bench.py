@@ -26,7 +26,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_LANE_OPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 
 
 def main():
@@ -138,11 +137,16 @@ def main():
         # the committed rocprofv3 --pmc measurement (profiles/, separate FETCH_SIZE and WRITE_SIZE passes of this same
         # command, KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) scaled per cell.
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_local16.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_local16.json")))
             k = pmc["stitch::fill_local16_kernel"]
             bpc = (2.0 * k["FETCH_SIZE"]["avg_per_launch_raw"] + k["WRITE_SIZE"]["avg_per_launch_raw"]) * 1024.0 / pmc["cells_per_launch"]
             out["roofline"]["traffic"] = bpc * cells / max(1, launches)
-            out["roofline"]["traffic_source"] = ("profiles/r01_c_pmc_local16.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch of "
+            # second view, as SURVEY.md 8(d) asks: integer VALU issue.  A wave64 integer instruction occupies its SIMD for 4 clocks
+            # (16 lanes/clock), so the ceiling is 256 CU x 4 SIMD x 2.4 GHz / 4 wave-instructions/s.
+            vpc = k["SQ_INSTS_VALU"]["avg_per_launch_raw"] * 64.0 / pmc["cells_per_launch"]
+            out["roofline"]["valu"] = {"wave_insts_per_64_cells": vpc, "achieved_wave_insts_per_s": vpc * (cells / 64.0) / fill_s,
+                                       "peak_wave_insts_per_s": 256 * 4 * 2.4e9 / 4, "frac": vpc * (cells / 64.0) / fill_s / (256 * 4 * 2.4e9 / 4)}
+            out["roofline"]["traffic_source"] = ("profiles/r01_d_pmc_local16.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch of "
                                                  f"{pmc['cells_per_launch']:.3g} cells = {bpc:.2f} B/cell, scaled to this run's cells per launch")
         except (OSError, KeyError, ValueError):
             pass
