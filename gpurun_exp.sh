@@ -1,12 +1,4 @@
-set -e
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r01d
-python bench.py > $R/gpurun_out/r01d/bench.json 2> $R/gpurun_out/r01d/bench.err
-tail -c 300 $R/gpurun_out/r01d/bench.json
-cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r01d/kt -o kt -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-reads 0 > $R/gpurun_out/r01d/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r01d/pmc_fetch -o pf -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-reads 0 > $R/gpurun_out/r01d/pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r01d/pmc_write -o pw -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-reads 0 > $R/gpurun_out/r01d/pw.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d $R/gpurun_out/r01d/pmc_sq -o ps -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-reads 0 > $R/gpurun_out/r01d/ps.log 2>&1
-echo ok
+timeout -k 5 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3
+for k in 1 2; do
+timeout -k 5 120 python bench.py --reads-per-step 64 --steps 2 --warmup 1 --cpu-reads 0 2>&1 | grep -i "reads_per" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   reads/s', round(d['value'],2), 'fill_ms', round(d['roofline']['avg_launch_ms'],1), 'walk', round(d['roofline']['walk_kernel_ms_per_step'],1))"
+done

@@ -122,20 +122,12 @@ __device__ __forceinline__ void wave_scan(ScanEl& inc) {   // inclusive scan wit
 // wave_scan leave the total in lane 63.  Lanes a step does not reach keep `identity`.
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false); }
-#ifdef STITCH_BPERM_REDUCE
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o > v ? o : v; }
-    return v;
-}
-#else
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     { const uint32_t o = dpp_u32<DPP_ROW_SHR0 | 1>(0u, v); v = o > v ? o : v; } { const uint32_t o = dpp_u32<DPP_ROW_SHR0 | 2>(0u, v); v = o > v ? o : v; }
     { const uint32_t o = dpp_u32<DPP_ROW_SHR0 | 4>(0u, v); v = o > v ? o : v; } { const uint32_t o = dpp_u32<DPP_ROW_SHR0 | 8>(0u, v); v = o > v ? o : v; }
     { const uint32_t o = dpp_u32<DPP_BCAST15, 0xA>(0u, v); v = o > v ? o : v; } { const uint32_t o = dpp_u32<DPP_BCAST31, 0xC>(0u, v); v = o > v ? o : v; }
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-#endif
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
 // max of 64-bit keys hi:lo as two 32-bit reductions: the largest hi, then the largest lo among the lanes that hold it
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
@@ -256,12 +248,7 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
         const int32_t F = row_phase_c_word(ra[u], bi, il, mv);
         code[u] = mv | (ext ? TBB_IEXT : 0u) | (ra[u].dext ? TBB_DEXT : 0u);
         Fo[u] = F;
-        if (!PARTIAL || i < m) {
-            const bool better = (uint32_t)F > acc.xw;                                 // rows ascend within a lane: first max wins (F >= 0)
-            acc.xw = better ? (uint32_t)F : acc.xw; acc.xrow = better ? i : acc.xrow;
-            const uint32_t ck = ((uint32_t)F & 0xFFFF0000u) | (0xFFFFu - i);
-            tk = ck > tk ? ck : tk;
-        }
+        if (!PARTIAL || i < m) tk = (uint32_t)F > tk ? (uint32_t)F : tk;               // the lane's largest S word of this tile (F >= 0)
         if (PARTIAL) {
             if (i == m) { rm.F = F; rm.mv = mv; rm.bits = code[u] & (TBB_IEXT | TBB_DEXT); rm.BD = ra[u].BD; rm.DG = ra[u].DG; }
             if (i > m) { Fo[u] = 0; ra[u].BD = word_make(-16384, 0); code[u] = 0; }
@@ -269,15 +256,20 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
         if (LASTCOL) { if (!PARTIAL || i <= m) { const GPtrsCold& C = *V.cold; C.S[r + u] = word_score(F); C.Slen[r + u] = word_len(F); C.Ival[r + u] = bi; C.Ilen[r + u] = il; } }
         ROW_FENCE
     }
-#ifdef STITCH_CKLEN_MEM
-    acc.ck = tk > acc.ck ? tk : acc.ck;
-#else
-    if (tk > acc.ck) {            // a new lane maximum (rare after a contig's first tiles: equal scores keep the lower row)
-        acc.ck = tk;
+    // Running records of the lane, updated per tile, not per row (rows ascend within a lane and across its tiles, so an equal
+    // value never replaces an earlier one; after a contig's first tiles these branches are rarely taken):
+    // x-suffix record = largest S word, first row holding it (:406-429)
+    if (tk > acc.xw) {
+        acc.xw = tk;
 #pragma unroll
-        for (int u = 0; u < R; ++u) if ((((uint32_t)Fo[u] & 0xFFFF0000u) | (0xFFFFu - (i0 + u))) == tk) acc.cklen = (uint32_t)Fo[u] & 0xFFFFu;
+        for (int u = R - 1; u >= 0; --u) if ((!PARTIAL || i0 + u < m) && (uint32_t)Fo[u] == tk) acc.xrow = i0 + u;
     }
-#endif
+    // column arg-max = largest score, first row holding it, and that row's length (:677-697)
+    if ((tk >> 16) > (acc.ck >> 16)) {
+#pragma unroll
+        for (int u = R - 1; u >= 0; --u)
+            if ((!PARTIAL || i0 + u < m) && ((uint32_t)Fo[u] >> 16) == (tk >> 16)) { acc.ck = (tk & 0xFFFF0000u) | (0xFFFFu - (i0 + u)); acc.cklen = (uint32_t)Fo[u] & 0xFFFFu; }
+    }
     // y-suffix trackers (:431-447): only cells that reach the contig's running maximum can matter.  Such a cell
     // has S >= vrun >= Sn (Sn is this row's maximum over earlier columns, vrun the contig's over the same columns; tests/emu
     // checks the invariant), so the reference's test `S > Sn || (S == Sn && len > 0)` is `len > 0`, i.e. the S word > 0, and
@@ -468,12 +460,8 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
         JumpBase* base_out = base2[j & 1];
         const gptr<uint8_t> tbcol = GP.tb + (size_t)(j - 1) * Rtot;
         // the read's bases, 64 columns per (coalesced) load: lane l holds y[jb + l]
-#ifdef STITCH_Y_DIRECT
-        const uint8_t q = (uint8_t)__builtin_amdgcn_readfirstlane((int)V.y[j - 1]);
-#else
         if (((j - 1) & 63u) == 0) ychunk = (j - 1 + lane < n) ? (uint32_t)V.y[j - 1 + lane] : 0u;
         const uint8_t q = (uint8_t)__builtin_amdgcn_readlane((int)ychunk, (int)((j - 1) & 63u));
-#endif
 
         WaveCol wc; LaneAcc acc; RowM rm;
         wc.j = j; wc.n = n; wc.q = (uint32_t)q;
@@ -604,12 +592,6 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
                 Sm = lane_bcast(Sm, owner_lane); Slm = (uint32_t)lane_bcast((int)Slm, owner_lane); mvm = (uint32_t)lane_bcast((int)mvm, owner_lane);
                 if (lane == 0) {
                     if (Sm > cb_.v) { cb_.v = Sm; cb_.row = m; cb_.len = Slm; }
-#ifdef STITCH_CKLEN_MEM
-                    else if (cb_.row != 0) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        cb_.len = __builtin_nontemporal_load(st + 2 * (size_t)(roff + cb_.row - 1)) & 0xFFFFu;
-                    }
-#endif
                     JumpBase b; b.score = cb_.v; b.len = cb_.len + 1; b.from = cb_.row;
                     base_out[c] = b;
                     if (G > 1) {
