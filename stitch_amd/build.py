@@ -39,6 +39,25 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+CLI_SRC = os.path.join(HERE, "cli", "stitch_align.cpp")
+CLI_PATH = os.path.join(HERE, "bin", "stitch-align")
+
+
+def build_cli(force=False):
+    """The `stitch align` front end (stitch_amd/cli/stitch_align.cpp): a plain C++ program over the C ABI."""
+    lib = build()
+    if not force and os.path.exists(CLI_PATH) and os.path.getmtime(CLI_PATH) > max(os.path.getmtime(CLI_SRC), os.path.getmtime(lib)):
+        return CLI_PATH
+    os.makedirs(os.path.dirname(CLI_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O2", "-std=c++17", "-o", CLI_PATH, CLI_SRC, "-L" + LIB_DIR, "-lstitch_amd", "-lz", "-Wl,-rpath,$ORIGIN/../lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building stitch-align failed:\n" + r.stdout)
+    return CLI_PATH
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     print(LIB_PATH)
+    print(build_cli(force="--force" in sys.argv))
