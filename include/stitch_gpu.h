@@ -33,7 +33,7 @@ typedef struct stitch_opts {
   int32_t match_score, mismatch_score, gap_open, gap_extend;
   int32_t jump_same, jump_opposite, jump_inter;      /* already defaulted from --jump-score  mod.rs:143-152 */
   int32_t double_strand, circular, circular_slop;
-  int32_t pre_align, pre_align_min_score, pre_align_subset_contigs, kmer_size, band_width;   /* accepted, see DESIGN.md */
+  int32_t pre_align, pre_align_min_score, pre_align_subset_contigs, kmer_size, band_width;   /* mod.rs:246-295; local mode, DESIGN.md A15 */
   int32_t suboptimal; float suboptimal_pct;
   int32_t soft_clip, use_eq_and_x, pick_primary /* 0 query-length, 1 score */, filter_secondary;
   float filter_secondary_pct;

@@ -190,16 +190,18 @@ class MultiContigAligner:
 def options_arrays(mode="local", match=1, mismatch=-4, gap_open=-6, gap_extend=-2, jump_score=-10, jump_same=None,
                    jump_opp=None, jump_inter=None, double_strand=False, circular=False, circular_slop=20,
                    suboptimal=False, suboptimal_pct=20.0, soft_clip=False, use_eq_and_x=False, pick_primary=0,
-                   filter_secondary=False, filter_secondary_pct=10.0):
+                   filter_secondary=False, filter_secondary_pct=10.0, pre_align=False, pre_align_min_score=100,
+                   pre_align_subset_contigs=True, kmer_size=12, band_width=50):
     """aligners/mod.rs:65-116 (defaults are the CLI's)."""
     o = (C.c_int32 * 24)()
     vals = [MODES[mode] if isinstance(mode, str) else mode, match, mismatch, gap_open, gap_extend, jump_score,
             int(jump_same is not None), jump_same or 0, int(jump_opp is not None), jump_opp or 0,
             int(jump_inter is not None), jump_inter or 0, int(double_strand), int(circular), circular_slop,
             int(suboptimal), int(soft_clip), int(use_eq_and_x), pick_primary, int(filter_secondary)]
+    vals += [int(pre_align), pre_align_min_score, int(pre_align_subset_contigs), kmer_size]
     for k, v in enumerate(vals):
         o[k] = v
-    f = (C.c_float * 2)(suboptimal_pct, filter_secondary_pct)
+    f = (C.c_float * 3)(suboptimal_pct, filter_secondary_pct, float(band_width))
     return o, f
 
 
@@ -236,6 +238,11 @@ class Aligners:
 
     def cells(self):
         return int(lib().orc_al_cells(self.h))
+
+    def prealign_score(self):
+        """The pre-alignment score of the last align() (None without --pre-align or when nothing passed)."""
+        v = C.c_int32(0)
+        return int(v.value) if lib().orc_al_prealign(self.h, C.byref(v)) else None
 
     def format_sam(self, head, bases, quals=None, prealign=None):
         """SamRecordFormatter::format on the chains of the last align() call -> list of SAM text lines."""

@@ -55,6 +55,8 @@ static Options get_options(const int32_t* o, const float* f) {
     op.double_strand = o[12]; op.circular = o[13]; op.circular_slop = (size_t)o[14];
     op.suboptimal = o[15]; op.soft_clip = o[16]; op.use_eq_and_x = o[17]; op.pick_primary = o[18]; op.filter_secondary = o[19];
     op.suboptimal_pct = f[0]; op.filter_secondary_pct = f[1];
+    op.pre_align = o[20]; op.pre_align_min_score = o[20] ? o[21] : 100; op.pre_align_subset_contigs = o[20] ? o[22] != 0 : true;
+    if (o[20]) { op.kmer_size = (size_t)o[23]; op.band_width = (size_t)f[2]; }
     return op;
 }
 
@@ -136,7 +138,7 @@ int orc_cell_apply(uint32_t* cell4, int op, uint32_t tb, uint32_t len, uint32_t 
 }
 
 // Aligners — aligners/mod.rs:171-553 (pre_align not restated)
-struct OrcAligners { Aligners al; std::vector<TargetSeq> targets; std::vector<Alignment> chains; };
+struct OrcAligners { Aligners al; std::vector<TargetSeq> targets; std::vector<Alignment> chains; std::optional<int32_t> prealign; };
 void* orc_al_new(const int32_t* opts, const float* fopts, size_t n_targets, const char* const* names,
                  const uint8_t* const* seqs, const size_t* lens) {
     try {
@@ -155,8 +157,18 @@ void* orc_al_new(const int32_t* opts, const float* fopts, size_t n_targets, cons
 void orc_al_free(void* h) { delete (OrcAligners*)h; }
 long orc_al_align(void* hh, const uint8_t* read, size_t n) {
     auto* h = (OrcAligners*)hh;
-    try { h->chains = h->al.align(read, n); return (long)h->chains.size(); }
+    try {
+        h->prealign.reset();
+        if (h->al.opts.pre_align) h->chains = h->al.align_prealign(read, n, h->targets, &h->prealign);
+        else h->chains = h->al.align(read, n);
+        return (long)h->chains.size();
+    }
     catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+// pre-alignment score of the last orc_al_align (the xs tag): returns 1 and sets *score, or 0 when there is none
+int orc_al_prealign(void* hh, int32_t* score) { auto* h = (OrcAligners*)hh; if (!h->prealign) return 0; *score = *h->prealign; return 1; }
+long orc_banded_local_score(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match, int32_t mismatch, int32_t go, int32_t ge) {
+    try { return banded_local_score(x, m, y, n, k, w, match, mismatch, go, ge); } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 long orc_al_chain(void* hh, size_t k, int64_t* out, size_t cap) {
     auto* h = (OrcAligners*)hh;

@@ -879,7 +879,12 @@ Alignment Aligners::multi_contig_align(const uint8_t* q, size_t n, const std::se
 std::vector<Alignment> Aligners::align(const uint8_t* read, size_t n) {   // :237-340 with pre_align == false
     std::vector<uint8_t> query(read, read + n);
     for (auto& b : query) if (b >= 'a' && b <= 'z') b = (uint8_t)(b - 32);   // seq_upper_case, io.rs:64-66
-    const std::set<uint32_t>* contigs_to_align = nullptr;
+    return align_subset(query.data(), n, nullptr);
+}
+
+// :289-337 — everything after the pre-alignment decision; `q` is already upper case
+std::vector<Alignment> Aligners::align_subset(const uint8_t* q, size_t n, const std::set<uint32_t>* contigs_to_align) {
+    std::vector<uint8_t> query(q, q + n);
     Alignment original = multi_contig_align(query.data(), n, contigs_to_align);
     std::vector<Alignment> alignments;
     if (opts.suboptimal) {

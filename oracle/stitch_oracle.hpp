@@ -202,9 +202,11 @@ struct Aligners {
     MultiContigAligner multi_contig;
     Options opts;
     static Aligners build(const Options& opts, const std::vector<TargetSeq>& target_seqs);   // :171-211
-    // pre-alignment (bio banded aligner) is NOT restated: callers pass the per-contig-index pre-align
-    // scores they want honoured (empty => behave as pre_align=false).  mod.rs:246-295
     std::vector<Alignment> align(const uint8_t* read, size_t n);                  // :237-340, pre_align=false
+    std::vector<Alignment> align_subset(const uint8_t* q, size_t n, const std::set<uint32_t>* contigs_to_align);   // :289-337
+    // :237-340 with pre_align (prealign_oracle.cpp: restated from bio's published description, parity unpinned)
+    std::vector<Alignment> align_prealign(const uint8_t* read, size_t n, const std::vector<TargetSeq>& target_seqs,
+                                          std::optional<int32_t>* prealign_score);
     Alignment remove_clipping(Alignment aln) const;                               // :343-353
     Alignment multi_contig_align(const uint8_t* q, size_t n, const std::set<uint32_t>* idx);   // :355-363
     Alignment realign_origin(const uint8_t* q, size_t n, Alignment alignment, size_t slop, bool all_contigs);  // :442-553
@@ -216,5 +218,9 @@ std::vector<std::string> format_sam(const Options& opts, const std::vector<Targe
                                     const std::string& head, const std::vector<uint8_t>& bases,
                                     const std::vector<uint8_t>* quals, const std::vector<Alignment>& chains,
                                     std::optional<int32_t> pre_alignment_score, std::string* err);
+
+// prealign_oracle.cpp: bio 1.1.0 pairwise::banded restated from its published description (parity unpinned)
+int32_t banded_local_score(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match,
+                           int32_t mismatch, int32_t go, int32_t ge);
 
 }  // namespace orc

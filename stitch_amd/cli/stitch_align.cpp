@@ -187,7 +187,7 @@ const char* USAGE =
     "  -d, --double-strand         align to both strands simultaneously\n"
     "  -t, --threads N             accepted for compatibility (the GPU does the work)\n"
     "  -z, --decompress            accepted for compatibility (gzip is detected)\n"
-    "  -p, --pre-align  -k K  -w W  -s SCORE  -x BOOL   banded pre-alignment filter (not implemented: rejected)\n"
+    "  -p, --pre-align  -k K  -w W  -s SCORE  -x BOOL   banded pre-alignment filter (local mode; k 12, w 50, score 100, subset true)\n"
     "  -S, --soft-clip             soft-clip secondary alignments too\n"
     "  -X, --use-eq-and-x          =/X CIGAR operators instead of M\n"
     "  -A/-B/-O/-E/-J N            match, mismatch, gap open, gap extend, jump scores (1 -4 -6 -2 -10)\n"
@@ -306,7 +306,6 @@ int main(int argc, char** argv) {
 
     if (a.ref_fasta.empty()) die(std::string("--ref-fasta is required\n") + USAGE);
     if (a.reads_fastq.empty() == a.reads_fasta.empty()) die("Must specify exactly one of --reads-fastq or --reads-fasta");
-    if (a.o.pre_align) die("--pre-align (banded pre-alignment filter) is not implemented by this library yet");
 
     // reference (target_seq::from_fasta): name = first word, sequence upper-cased by the library
     std::vector<std::string> names, seqs;

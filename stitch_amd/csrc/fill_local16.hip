@@ -142,6 +142,16 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // pairs) live at once, far beyond the 102 SGPRs of a wave, i.e. v_writelane/v_readlane spill traffic in the inner loop.
 // At two waves per SIMD a wave only gets every other issue slot anyway, so nothing is lost by finishing one row before the
 // next: the fence keeps the schedule row-serial.
+#if defined(STITCH_PAIR_FENCE_A)
+#define ROW_FENCE_A(u) if ((u) & 1) __builtin_amdgcn_sched_barrier(0);
+#else
+#define ROW_FENCE_A(u) ROW_FENCE
+#endif
+#if defined(STITCH_PAIR_FENCE_C)
+#define ROW_FENCE_C(u) if ((u) & 1) __builtin_amdgcn_sched_barrier(0);
+#else
+#define ROW_FENCE_C(u) ROW_FENCE
+#endif
 #ifndef STITCH_NO_ROW_FENCE
 #define ROW_FENCE __builtin_amdgcn_sched_barrier(0);
 #else
@@ -201,7 +211,7 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
     for (int u = 0; u < R; ++u) {
         const bool row1 = (u == 0) && (i0 == 1);
         row_phase_a_word(xb[u] == wc.q ? K.MW : K.XW, K.GE1, K.GO1, row1 ? wc.JSW1 : wc.JSW, u == 0 ? nS : Sp[u - 1], Sp[u], Dp[u], ra[u]);
-        ROW_FENCE
+        ROW_FENCE_A(u)
     }
     // The previous column's words are dead from here on: the NEXT slot's state is loaded into the same registers and lands
     // during phases B and C (one register buffer; the wait is at the top of the next slot).
@@ -255,7 +265,7 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
             if (i > m) { Fo[u] = 0; ra[u].BD = word_make(-16384, 0); code[u] = 0; }
         }
         if (LASTCOL) { if (!PARTIAL || i <= m) { const GPtrsCold& C = *V.cold; C.S[r + u] = word_score(F); C.Slen[r + u] = word_len(F); C.Ival[r + u] = bi; C.Ilen[r + u] = il; } }
-        ROW_FENCE
+        ROW_FENCE_C(u)
     }
     // Running records of the lane, updated per tile, not per row (rows ascend within a lane and across its tiles, so an equal
     // value never replaces an earlier one; after a contig's first tiles these branches are rarely taken):
@@ -400,10 +410,16 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
         uint32_t NT = 0;
         for (uint32_t k = part; k < nact; k += G) NT += (V.cd[V.act[k]].m + TILE - 1) / TILE;
         if (NT > MAXSLOTS) NT = MAXSLOTS;                     // (the host keeps NT within the table)
+        // weights -> tile boundaries.  No wave of the first min(W, NT) may get an empty range: a contig's pieces are numbered
+        // by consecutive waves, and a wave waits for the piece number before its own (an empty range in between would never
+        // publish it).
+        for (int w = W; w >= 0; --w) s_bnd[w] = (uint32_t)((unsigned long long)NT * s_bnd[w] / wsum);
+        if (NT >= (uint32_t)W) { for (int w = 1; w < W; ++w) { const uint32_t lo_ = s_bnd[w - 1] + 1, hi_ = NT - (uint32_t)(W - w); s_bnd[w] = s_bnd[w] < lo_ ? lo_ : s_bnd[w] > hi_ ? hi_ : s_bnd[w]; } }
+        else for (int w = 0; w <= W; ++w) s_bnd[w] = (uint32_t)w < NT ? (uint32_t)w : NT;
         // tile g of the workgroup -> (contig, tile): walk once, emitting records in global order into s_slots[...] scratch order
         uint32_t ns = 0;
         for (int w = 0; w < W; ++w) {
-            const uint32_t lo = (uint32_t)((unsigned long long)NT * s_bnd[w] / wsum), hi = (uint32_t)((unsigned long long)NT * s_bnd[w + 1] / wsum);
+            const uint32_t lo = s_bnd[w], hi = s_bnd[w + 1];
             s_wbeg[w] = ns;
             // locate (contig, tile) of global tile index `lo`
             uint32_t g = 0, kk = part, t0 = 0;
@@ -423,7 +439,7 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
                         // piece number of this wave's part of the contig: waves between the one holding tile 0 and this one
                         const uint32_t gstart = x - t;                                   // global index of the contig's tile 0
                         uint32_t w0 = (uint32_t)w;                                       // the wave whose range holds gstart
-                        while (w0 > 0 && (uint32_t)((unsigned long long)NT * s_bnd[w0] / wsum) > gstart) --w0;
+                        while (w0 > 0 && s_bnd[w0] > gstart) --w0;
                         rec.w = (uint32_t)w - w0;
                         s_slots[ns++] = rec;
                     }
@@ -515,7 +531,13 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
                 // continue a contig another wave started in this column: wait for its carries (same workgroup, always resident)
                 c = e & 0xFFu;
                 const uint32_t want = (j << 8) | (piece & 0xFFu);      // (column, piece)
-                while (__hip_atomic_load(&s_cflag[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
+                {   // bounded: a hand-off that never comes must end the kernel with an error, not hang the GPU
+                    const unsigned long long t0 = wall_clock64();
+                    while (__hip_atomic_load(&s_cflag[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
+                        if (wall_clock64() - t0 > 400000000ull || __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { s_abort = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
                 wc.upS = __builtin_amdgcn_readfirstlane(s_carry[c][0]); wc.upT = __builtin_amdgcn_readfirstlane(s_carry[c][1]);
                 wc.carry.key = __builtin_amdgcn_readfirstlane(s_carry[c][2]); wc.carry.q = __builtin_amdgcn_readfirstlane(s_carry[c][3]);
                 wc.JSW = __builtin_amdgcn_readfirstlane(s_carry[c][4]); wc.JSW1 = __builtin_amdgcn_readfirstlane(s_carry[c][5]);
@@ -619,6 +641,7 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
         PROF(3)
         __syncthreads();
         PROF(7)
+        if (G == 1 && s_abort) { if (threadIdx.x == 0) *V.err = 1; return true; }
         if (G > 1) {
             // gather the other workgroups' records of column j (bounded spin: a missing partner must not hang the GPU)
             for (uint32_t k = threadIdx.x; k < nact; k += blockDim.x) {

@@ -1,0 +1,106 @@
+// Host side of the banded pre-alignment filter: k-mer matches, backbone chain, band (see prealign.h for the provenance).
+#include "prealign.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace stitch {
+
+namespace {
+constexpr size_t MAX_MATCHES = 65536;          // beyond this the pair is scored over the full matrix
+
+inline uint64_t kmer_hash(const uint8_t* p, uint32_t k) {      // FNV-1a; equality is always re-checked on the bytes
+    uint64_t h = 1469598103934665603ull;
+    for (uint32_t a = 0; a < k; ++a) { h ^= p[a]; h *= 1099511628211ull; }
+    return h;
+}
+}  // namespace
+
+KmerIndex build_kmer_index(const uint8_t* t, uint32_t n, uint32_t k) {
+    KmerIndex ix; ix.k = k;
+    if (k == 0 || n < k) return ix;
+    const uint32_t cnt = n - k + 1;
+    std::vector<uint64_t> h(cnt);
+    for (uint32_t j = 0; j < cnt; ++j) h[j] = kmer_hash(t + j, k);
+    std::vector<uint32_t> ord(cnt); std::iota(ord.begin(), ord.end(), 0u);
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return h[a] != h[b] ? h[a] < h[b] : a < b; });
+    ix.key.resize(cnt); ix.pos.resize(cnt);
+    for (uint32_t a = 0; a < cnt; ++a) { ix.key[a] = h[ord[a]]; ix.pos[a] = ord[a]; }
+    return ix;
+}
+
+void make_band(const uint8_t* q, uint32_t m, const uint8_t* t, uint32_t n, const KmerIndex& ix, uint32_t w, int32_t match,
+               int32_t gap_open, int32_t gap_extend, std::vector<uint16_t>& lo, std::vector<uint16_t>& hi) {
+    const uint32_t k = ix.k;
+    lo.assign(n + 1, (uint16_t)(m + 1)); hi.assign(n + 1, 0);
+    auto full = [&]() { std::fill(lo.begin(), lo.end(), (uint16_t)0); std::fill(hi.begin(), hi.end(), (uint16_t)(m + 1)); };
+
+    // 1. exact k-mer matches, ordered by (query start, target start)
+    struct Seed { uint32_t i, j; };
+    std::vector<Seed> seeds;
+    if (k > 0 && m >= k && !ix.key.empty()) {
+        for (uint32_t i = 0; i + k <= m && seeds.size() <= MAX_MATCHES; ++i) {
+            const uint64_t h = kmer_hash(q + i, k);
+            auto a = std::lower_bound(ix.key.begin(), ix.key.end(), h);
+            for (; a != ix.key.end() && *a == h; ++a) {
+                const uint32_t j = ix.pos[(size_t)(a - ix.key.begin())];
+                if (memcmp(q + i, t + j, k) == 0) seeds.push_back(Seed{i, j});
+            }
+        }
+    }
+    if (seeds.empty() || seeds.size() > MAX_MATCHES) { full(); return; }
+
+    // 2. backbone: best-scoring chain of seeds (k * match per seed, + match for a seed that continues the one a step up the
+    //    diagonal, gap penalty -gap_open - gap_extend * d for d = max(query gap, target gap) > 0); first best wins
+    const size_t Q = seeds.size();
+    std::vector<long long> best(Q); std::vector<int> from(Q, -1);
+    const long long seed_score = (long long)k * match;
+    for (size_t b = 0; b < Q; ++b) {
+        const Seed sb = seeds[b];
+        long long v = seed_score; int f = -1;
+        if (sb.i > 0 && sb.j > 0) {                        // continuation: binary search among the earlier seeds
+            size_t lo_ = 0, hi_ = b;
+            while (lo_ < hi_) { const size_t mid = (lo_ + hi_) / 2; const Seed s = seeds[mid]; if (s.i < sb.i - 1 || (s.i == sb.i - 1 && s.j < sb.j - 1)) lo_ = mid + 1; else hi_ = mid; }
+            if (lo_ < b && seeds[lo_].i == sb.i - 1 && seeds[lo_].j == sb.j - 1 && best[lo_] + match > v) { v = best[lo_] + match; f = (int)lo_; }
+        }
+        for (size_t a = 0; a < b; ++a) {
+            const Seed sa = seeds[a];
+            if (sa.i + k > sb.i) break;                    // seeds are ordered by i: nothing later can precede sb either
+            if (sa.j + k > sb.j) continue;
+            const long long gi = (long long)sb.i - sa.i - k, gj = (long long)sb.j - sa.j - k, d = std::max(gi, gj);
+            const long long cand = best[a] + seed_score - (d > 0 ? -(long long)gap_open - (long long)gap_extend * d : 0);
+            if (cand > v) { v = cand; f = (int)a; }
+        }
+        best[b] = v; from[b] = f;
+    }
+    size_t end = 0;
+    for (size_t b = 1; b < Q; ++b) if (best[b] > best[end]) end = b;
+    std::vector<uint32_t> chain;
+    for (int b = (int)end; b >= 0; b = from[b]) chain.push_back((uint32_t)b);
+    std::reverse(chain.begin(), chain.end());
+
+    // 3. band around the backbone
+    auto add = [&](long r, long c) {
+        const long c0 = std::max<long>(c - (long)w, 0), c1 = std::min<long>(c + (long)w, (long)n);
+        const uint16_t r0 = (uint16_t)std::max<long>(r - (long)w, 0), r1 = (uint16_t)(std::min<long>(r + (long)w, (long)m) + 1);
+        for (long cc = c0; cc <= c1; ++cc) { if (r0 < lo[cc]) lo[cc] = r0; if (r1 > hi[cc]) hi[cc] = r1; }
+    };
+    for (size_t p = 0; p < chain.size(); ++p) {
+        const Seed s = seeds[chain[p]];
+        for (uint32_t a = 0; a <= k; ++a) add((long)s.i + a, (long)s.j + a);
+        if (p + 1 < chain.size()) {
+            const Seed nx = seeds[chain[p + 1]];
+            const long ai = (long)s.i + k, aj = (long)s.j + k;
+            if ((long)nx.i >= ai && (long)nx.j >= aj) {
+                const long gi = (long)nx.i - ai, gj = (long)nx.j - aj, steps = std::max(gi, gj);
+                for (long a = 1; a < steps; ++a) add(ai + gi * a / steps, aj + gj * a / steps);
+            }
+        }
+    }
+    { const Seed s = seeds[chain.front()]; for (long a = 1; a <= (long)std::min(s.i, s.j); ++a) add((long)s.i - a, (long)s.j - a); }
+    { const Seed s = seeds[chain.back()]; const long ie = (long)s.i + k, je = (long)s.j + k;
+      for (long a = 1; a <= std::min((long)m - ie, (long)n - je); ++a) add(ie + a, je + a); }
+}
+
+}  // namespace stitch

@@ -22,8 +22,11 @@
 #include "dp_core.h"
 #include "host_align.h"
 #include "walk_core.h"
+#include "prealign.h"
 
 namespace stitch {
+void launch_banded_scores(const BandPair* d_pairs, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
+                          const uint16_t* d_bands, int32_t* d_state, int32_t* d_scores, hipStream_t stream);
 struct FillShared {
     const int32_t* S0; const uint32_t* Slen0; const int32_t* Sn0; const uint8_t* SnSet0; const uint8_t* Smove0;
     const uint32_t* lx0; const JumpBase* base0;
@@ -79,6 +82,9 @@ struct stitch_ctx {
     int n_cus = 256; uint32_t tm_wg_per_read = 1;
     bool tm_fast = false;                        // last run_jobs used the Local-mode 16-bit kernel
     size_t mem_limit = 0;                        // optional cap on arena bytes (STITCH_ARENA_BYTES), for tests
+    // banded pre-alignment filter (prealign.h): host copies of the contig strands, their k-mer indexes, device scratch
+    std::vector<uint8_t> h_xseq; std::vector<KmerIndex> kidx;
+    uint8_t* pre_buf = nullptr; size_t pre_bytes = 0;
 };
 
 static std::vector<uint8_t> revcomp(const std::vector<uint8_t>& s) {             // util/dna.rs:5-41
@@ -168,7 +174,7 @@ int stitch_index_deserialize(const void* buf, size_t len, stitch_index** out) {
 void stitch_ctx_destroy(stitch_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_xseq, c->d_S0, c->d_Slen0, c->d_Sn0, c->d_SnSet0, c->d_Smove0, c->d_Imove0, c->d_lx0, c->d_base0, c->arena};
+    void* ptrs[] = {c->d_xseq, c->d_S0, c->d_Slen0, c->d_Sn0, c->d_SnSet0, c->d_Smove0, c->d_Imove0, c->d_lx0, c->d_base0, c->arena, c->pre_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -182,7 +188,8 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     if (o->gap_open > 0) return fail(STITCH_EINVAL, "gap_open can't be positive");
     if (o->gap_extend > 0) return fail(STITCH_EINVAL, "gap_extend can't be positive");
     if (o->jump_same > 0 || o->jump_opposite > 0 || o->jump_inter > 0) return fail(STITCH_EINVAL, "jump scores can't be positive");
-    if (o->pre_align) return fail(STITCH_EINVAL, "pre_align (bio banded pre-filter) is not implemented in this build; see DESIGN.md");
+    if (o->pre_align && o->mode != 0) return fail(STITCH_EINVAL, "pre_align is implemented for local mode only (bio's banded aligner is restated from its published description, see DESIGN.md A15)");
+    if (o->pre_align && (o->kmer_size < 1 || o->band_width < 0)) return fail(STITCH_EINVAL, "bad k-mer size or band width");
     const uint32_t T = (uint32_t)idx->names.size();
     const uint32_t C = T * (o->double_strand ? 2u : 1u);
     if (C > 255) return fail(STITCH_EINVAL, "more than 255 contig-strands (packed_length_cell.rs:112-114)");
@@ -250,6 +257,13 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal)); c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
     HIP_TRY(hipStreamCreate(&c->stream));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    if (o->pre_align) {
+        c->h_xseq = xseq;
+        for (uint32_t a = 0; a < C; ++a) c->kidx.push_back(build_kmer_index(c->h_xseq.data() + c->al[a].seqoff, c->al[a].m, (uint32_t)o->kmer_size));
+        c->pre_bytes = (size_t)1 << 30;
+        if (const char* e = getenv("STITCH_PREALIGN_BYTES")) c->pre_bytes = std::max<size_t>((size_t)1 << 20, (size_t)strtoull(e, nullptr, 10));
+        HIP_TRY(hipMalloc((void**)&c->pre_buf, c->pre_bytes));
+    }
     if (const char* lim = getenv("STITCH_ARENA_BYTES")) c->mem_limit = (size_t)strtoull(lim, nullptr, 10);
     *out = c.release();
     return STITCH_OK;
@@ -460,9 +474,9 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
             static const char* nm[8] = {"gather/loop", "select", "barrier1", "slot-setup", "tile", "finalize", "tile_wait", "barrier2"};
             for (int w = 0; w < waves; ++w) { fprintf(stderr, "[prof] wave %d:", w); for (int k = 0; k < 8; ++k) { if (k == 1) fprintf(stderr, " simd=%u slot=%u cu=%u", (unsigned)((pf[w * 8 + 1] >> 4) & 3), (unsigned)(pf[w * 8 + 1] & 15), (unsigned)((pf[w * 8 + 1] >> 8) & 15)); else fprintf(stderr, " %s=%.1fM", nm[k], pf[w * 8 + k] / 1e6); } fprintf(stderr, "\n"); }
         }
-        if (fast && G > 1) for (uint32_t q = 0; q < nj; ++q) {
+        if (fast) for (uint32_t q = 0; q < nj; ++q) {
             uint32_t e = 0; HIP_TRY(hipMemcpy(&e, views[q].err, 4, hipMemcpyDeviceToHost));
-            if (e) return fail(STITCH_EINTERNAL, "a workgroup timed out waiting for its partners (workgroups of one read were not co-resident)");
+            if (e) return fail(STITCH_EINTERNAL, "the fill kernel timed out waiting for a partner (workgroups of one read not co-resident, or a lost hand-off between waves)");
         }
 
         // download chains
@@ -504,6 +518,80 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
             }
         }
         c.tm.d2h_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d2h0).count();
+        k0 = k1;
+    }
+    return STITCH_OK;
+}
+
+// The pre-alignment filter of Aligners::align (mod.rs:246-295): banded local score of every (read, target strand) pair on the
+// device, then the reference's keep / early-break / subset logic on the host.  Sets jobs[k].act and the xs score.
+int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& has, std::vector<int32_t>& score) {
+    HIP_TRY(hipSetDevice(c.device));
+    const uint32_t C = c.C, T = c.T;
+    const BandScoring sc{c.opts.match_score, c.opts.mismatch_score, c.opts.gap_open, c.opts.gap_extend};
+    has.assign(jobs.size(), 0); score.assign(jobs.size(), 0);
+    auto al256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t k0 = 0;
+    while (k0 < jobs.size()) {
+        // as many reads as the scratch buffer holds
+        size_t k1 = k0, bytes = 0;
+        while (k1 < jobs.size()) {
+            const size_t m = jobs[k1].y.size();
+            if (m > 65534) return fail(STITCH_EINVAL, "pre_align: reads longer than 65534 bases are not supported");
+            size_t need = al256(m);
+            for (uint32_t a = 0; a < C; ++a) need += al256(4ull * (c.al[a].m + 1)) + al256(12ull * (m + 1)) + sizeof(BandPair) + 4;
+            if (bytes + need + 4096 > c.pre_bytes) break;
+            bytes += need; ++k1;
+        }
+        if (k1 == k0) return fail(STITCH_ENOMEM, "pre_align: one read does not fit in the pre-alignment scratch (STITCH_PREALIGN_BYTES)");
+        const size_t nj = k1 - k0, np = nj * C;
+        std::vector<uint8_t> h_reads; std::vector<uint16_t> h_bands; std::vector<BandPair> pairs(np);
+        size_t state_elems = 0;
+        std::vector<uint16_t> lo, hi;
+        for (size_t q = 0; q < nj; ++q) {
+            const Job& jb = jobs[k0 + q];
+            const uint64_t q_off = h_reads.size();
+            h_reads.insert(h_reads.end(), jb.y.begin(), jb.y.end());
+            for (uint32_t a = 0; a < C; ++a) {
+                const Aligner& A = c.al[a];
+                make_band(jb.y.data(), (uint32_t)jb.y.size(), c.h_xseq.data() + A.seqoff, A.m, c.kidx[a], (uint32_t)c.opts.band_width, c.opts.match_score,
+                          c.opts.gap_open, c.opts.gap_extend, lo, hi);
+                BandPair& P = pairs[q * C + a];
+                P.m = (uint32_t)jb.y.size(); P.n = A.m; P.q_off = q_off; P.t_off = A.seqoff;
+                P.band_off = h_bands.size(); h_bands.insert(h_bands.end(), lo.begin(), lo.end()); h_bands.insert(h_bands.end(), hi.begin(), hi.end());
+                P.state_off = state_elems; state_elems += 3ull * (P.m + 1);
+            }
+        }
+        uint8_t* p = c.pre_buf;
+        uint8_t* d_reads = p; p += al256(h_reads.size());
+        uint16_t* d_bands = (uint16_t*)p; p += al256(h_bands.size() * 2);
+        BandPair* d_pairs = (BandPair*)p; p += al256(np * sizeof(BandPair));
+        int32_t* d_scores = (int32_t*)p; p += al256(np * 4);
+        int32_t* d_state = (int32_t*)p; p += al256(state_elems * 4);
+        if ((size_t)(p - c.pre_buf) > c.pre_bytes) return fail(STITCH_EINTERNAL, "pre-alignment scratch overflow");
+        HIP_TRY(hipMemcpyAsync(d_reads, h_reads.data(), h_reads.size(), hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemcpyAsync(d_bands, h_bands.data(), h_bands.size() * 2, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemcpyAsync(d_pairs, pairs.data(), np * sizeof(BandPair), hipMemcpyHostToDevice, c.stream));
+        launch_banded_scores(d_pairs, (uint32_t)np, sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream);
+        HIP_TRY(hipGetLastError());
+        std::vector<int32_t> sco(np);
+        HIP_TRY(hipMemcpyAsync(sco.data(), d_scores, np * 4, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        for (size_t q = 0; q < nj; ++q) {
+            Job& jb = jobs[k0 + q];
+            std::vector<uint32_t> kept; int32_t best = 0; bool any = false;
+            for (uint32_t t = 0; t < T; ++t) {                                     // targets in order, forward then reverse complement (:249-279)
+                const int32_t f = sco[q * C + t];
+                if (f >= c.opts.pre_align_min_score) { kept.push_back(t); best = any ? std::max(best, f) : f; any = true; }
+                if (c.opts.double_strand) {
+                    const int32_t r = sco[q * C + T + t];
+                    if (r >= c.opts.pre_align_min_score) { kept.push_back(T + t); best = any ? std::max(best, r) : r; any = true; }
+                }
+                if (!c.opts.pre_align_subset_contigs && any) break;                // :276-278
+            }
+            has[k0 + q] = any ? 1 : 0; score[k0 + q] = best;
+            if (any && c.opts.pre_align_subset_contigs) { std::sort(kept.begin(), kept.end()); jb.act = kept; }
+        }
         k0 = k1;
     }
     return STITCH_OK;
@@ -623,7 +711,18 @@ int stitch_align_batch(stitch_ctx* c, const uint8_t* bases, const uint64_t* offs
         job_of[r] = (uint32_t)jobs.size();
         jobs.push_back(std::move(jb));
     }
-    int rc = run_jobs(*c, jobs);
+    int rc;
+    // pre-alignment filter (mod.rs:246-287): reads without a passing target are not aligned at all; with
+    // pre_align_subset_contigs the others are aligned to the passing contig-strands only
+    const size_t n_jobs_all = jobs.size();
+    std::vector<uint8_t> pre_has; std::vector<int32_t> pre_score; std::vector<size_t> live_of;
+    if (c->opts.pre_align) {
+        rc = run_prealign(*c, jobs, pre_has, pre_score); if (rc) return rc;
+        std::vector<Job> live;
+        for (size_t k = 0; k < jobs.size(); ++k) if (pre_has[k]) { live_of.push_back(k); live.push_back(std::move(jobs[k])); }
+        jobs.swap(live);
+    } else { live_of.resize(jobs.size()); for (size_t k = 0; k < jobs.size(); ++k) live_of[k] = k; }
+    rc = run_jobs(*c, jobs);
     if (rc) return rc;
 
     // host: chains of pass 1, realign planning
@@ -653,9 +752,14 @@ int stitch_align_batch(stitch_ctx* c, const uint8_t* bases, const uint64_t* offs
     }
     // result arena, input order
     c->rr.resize(n_reads);
+    std::vector<long> live_idx(n_jobs_all, -1);
+    for (size_t l = 0; l < live_of.size(); ++l) live_idx[live_of[l]] = (long)l;
+    static const std::vector<HAln> none;
     for (uint32_t r = 0; r < n_reads; ++r) {
-        const std::vector<HAln>& al = pj[job_of[r]].chains;
+        const long l = live_idx[job_of[r]];
+        const std::vector<HAln>& al = l >= 0 ? pj[(size_t)l].chains : none;
         stitch_read_result& R = c->rr[r]; memset(&R, 0, sizeof(R));
+        if (c->opts.pre_align && pre_has[job_of[r]]) { R.has_prealign = 1; R.prealign_score = pre_score[job_of[r]]; }
         R.chains_begin = c->chains.size(); R.n_chains = (uint32_t)al.size();
         for (const HAln& a : al) {
             stitch_chain ch{}; ch.score = a.score; ch.xstart = a.xstart; ch.xend = a.xend; ch.ystart = a.ystart; ch.yend = a.yend; ch.xlen = a.xlen; ch.ylen = a.ylen;

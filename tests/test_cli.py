@@ -59,14 +59,12 @@ def test_dry_run_parses_inputs_and_writes_the_header(cli, tmp_path, gz):
     assert b"2 targets, 2 reads, 16 bases" in r.stderr
 
 
-def test_fasta_reads_and_prealign_rejection(cli, tmp_path):
+def test_fasta_reads(cli, tmp_path):
     ref, _ = write_inputs(tmp_path)
     fa = tmp_path / "reads.fa"
     fa.write_text(">r1\nACGT\nACGT\n>r2\nGG\n")
-    r = run(cli, "-a", str(fa), "-r", ref, "--dry-run")
+    r = run(cli, "-a", str(fa), "-r", ref, "--dry-run", "-p", "-k", "10", "-w", "20", "-s", "30", "-x", "false")
     assert b"2 reads, 10 bases" in r.stderr
-    r = run(cli, "-a", str(fa), "-r", ref, "-p", check=False)
-    assert r.returncode == 2 and b"not implemented" in r.stderr
 
 
 def read_bam(data):
@@ -137,7 +135,7 @@ def test_bam_encoder(cli, tmp_path, level):
 
 # ---- end to end on the GPU: SAM text of the CLI == the oracle's SamRecordFormatter, read by read --------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["-d", "--suboptimal", "-X"], ["-C", "-S", "-P", "score"]])
+@pytest.mark.parametrize("extra", [[], ["-d", "--suboptimal", "-X"], ["-C", "-S", "-P", "score"], ["-p", "-k", "10", "-w", "25", "-s", "40", "-d"]])
 def test_cli_matches_oracle_sam(cli, tmp_path, extra):
     import random
     from oracle import oracle as orc
@@ -157,11 +155,13 @@ def test_cli_matches_oracle_sam(cli, tmp_path, extra):
     got = [l for l in out if not l.startswith("@")]
     opts = dict(double_strand="-d" in extra, suboptimal="--suboptimal" in extra, use_eq_and_x="-X" in extra, circular="-C" in extra,
                 soft_clip="-S" in extra, pick_primary=1 if "score" in extra else 0)
+    if "-p" in extra:
+        opts.update(pre_align=True, kmer_size=10, band_width=25, pre_align_min_score=40)
     o = orc.Aligners([(n, s.decode()) for n, s in db], **opts)
     want = []
     for k, (r, q) in enumerate(zip(reads, quals)):
         o.align(r)
-        want += o.format_sam(f"read_{k} x y", r, q)
+        want += o.format_sam(f"read_{k} x y", r, q, prealign=o.prealign_score())
     assert got == want
     # the BAM route carries the same records
     text, refs, recs = read_bam(run(cli, "-f", str(fq), "-r", str(ref), "--output-format", "bam", "-c", "1", *extra).stdout)

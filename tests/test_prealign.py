@@ -1,0 +1,148 @@
+"""A15: the banded pre-alignment filter (`--pre-align`).  The arithmetic belongs to crate bio 1.1.0, which is not in the
+reference tree and which no reference test pins: PARITY UNPINNED.  The oracle (oracle/prealign_oracle.cpp) restates the
+crate's published algorithm; these tests pin the oracle's definition with known answers and compare the product (host
+chaining + banded kernel) with it."""
+import ctypes as C
+import os
+import random
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as orc  # noqa: E402
+
+
+def banded(x, y, k=12, w=50, match=1, mismatch=-4, go=-6, ge=-2):
+    L = orc.lib()
+    L.orc_banded_local_score.restype = C.c_long
+    xb = (C.c_uint8 * max(1, len(x))).from_buffer_copy((x or "\0").encode())
+    yb = (C.c_uint8 * max(1, len(y))).from_buffer_copy((y or "\0").encode())
+    return L.orc_banded_local_score(xb, C.c_size_t(len(x)), yb, C.c_size_t(len(y)), C.c_size_t(k), C.c_size_t(w), match, mismatch, go, ge)
+
+
+def sw(x, y, match=1, mismatch=-4, go=-6, ge=-2):
+    """plain affine-gap Smith-Waterman score (Gotoh), the band-free answer"""
+    NEG = -10**9
+    H = [0] * (len(y) + 1); D = [NEG] * (len(y) + 1)
+    best = 0
+    for i in range(1, len(x) + 1):
+        diag, H[0], I = H[0], 0, NEG
+        for j in range(1, len(y) + 1):
+            D[j] = max(D[j] + ge, H[j] + go + ge)
+            I = max(I + ge, H[j - 1] + go + ge)
+            h = max(0, diag + (match if x[i - 1] == y[j - 1] else mismatch), D[j], I)
+            diag, H[j] = H[j], h
+            best = max(best, h)
+    return best
+
+
+def rnd(rng, n):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def mutate(rng, s, sub=0.03, ins=0.02, dele=0.02):
+    out = []
+    for ch in s:
+        r = rng.random()
+        if r < dele:
+            continue
+        out.append(rng.choice("ACGT") if r < dele + sub else ch)
+        if rng.random() < ins:
+            out.append(rng.choice("ACGT"))
+    return "".join(out)
+
+
+def test_known_answers():
+    rng = random.Random(3)
+    y = rnd(rng, 400)
+    assert banded(y[100:300], y) == 200                       # exact substring: every base matches
+    assert banded(rnd(rng, 50) + y[100:300] + rnd(rng, 70), y) >= 200
+    assert banded("ACGT", y, k=12) == sw("ACGT", y)           # no 12-mer fits: full matrix
+    assert banded("", y) == 0 and banded(y, "") == 0
+    x = y[50:150] + y[160:260]                                # one 10-base deletion: 200 matches - (6 + 2*10)
+    assert banded(x, y) == sw(x, y) == 200 - 26
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_band_covers_the_optimum_on_noisy_reads(seed):
+    """With a reasonable seed density and w above the path's excursion the banded score equals Smith-Waterman (the
+    property the crate documents); a band can never beat it."""
+    rng = random.Random(100 + seed)
+    y = rnd(rng, rng.randint(300, 700))
+    a = rng.randint(0, len(y) // 3); b = rng.randint(2 * len(y) // 3, len(y))
+    x = rnd(rng, rng.randint(0, 60)) + mutate(rng, y[a:b]) + rnd(rng, rng.randint(0, 60))
+    full = sw(x, y)
+    assert banded(x, y, k=8, w=30) == full
+    assert banded(x, y, k=8, w=0) <= full
+    other = rnd(rng, 500)
+    assert banded(x, other, k=8, w=30) <= sw(x, other)
+
+
+def test_oracle_aligners_prealign_logic():
+    rng = random.Random(9)
+    targets = [(f"t{k}", rnd(rng, 500)) for k in range(4)]
+    read = rnd(rng, 30) + mutate(rng, targets[2][1][100:400]) + rnd(rng, 30)
+    o = orc.Aligners(targets, pre_align=True, pre_align_min_score=60, kmer_size=10, band_width=20)
+    chains = o.align(read)
+    assert len(chains) == 1 and chains[0].start_contig_idx == 2 and o.prealign_score() == banded(read, targets[2][1], k=10, w=20)
+    assert o.align(rnd(rng, 200)) == [] and o.prealign_score() is None          # nothing passes: unmapped, no score
+    # without sub-setting every contig takes part again, and the loop stops at the first passing target
+    o2 = orc.Aligners(targets, pre_align=True, pre_align_min_score=60, pre_align_subset_contigs=False, kmer_size=10, band_width=20)
+    o3 = orc.Aligners(targets)
+    assert [c.key() for c in o2.align(read)] == [c.key() for c in o3.align(read)]
+    with pytest.raises(RuntimeError):
+        orc.Aligners(targets, pre_align=True, mode="global").align(read)
+
+
+# ---- product vs oracle ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [dict(), dict(double_strand=True), dict(pre_align_subset_contigs=False, double_strand=True),
+                                  dict(suboptimal=True, double_strand=True), dict(kmer_size=8, band_width=5, pre_align_min_score=30),
+                                  dict(circular=True)])
+def test_prealign_matches_oracle(opts):
+    import stitch_amd
+    from stitch_amd import synth
+    rng = random.Random(21)
+    db = synth.make_db(6, 700, 5)
+    targets = [(n, s.decode()) for n, s in db]
+    reads = [r.decode() for r in synth.make_reads(db, 14, 400, 8, both_strands=opts.get("double_strand", False), random_frac=0.3)]
+    reads += [rnd(rng, 40), targets[1][1][10:150], "ACGT" * 30]
+    base = dict(pre_align=True, pre_align_min_score=50, kmer_size=10, band_width=25)
+    base.update(opts)
+    al = stitch_amd.Builder(**base).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in targets], device=0)
+    got = al.align(reads)
+    o = orc.Aligners(targets, **base)
+    n_unmapped = 0
+    for k, read in enumerate(reads):
+        want = o.align(read)
+        ps = o.prealign_score()
+        assert got[k][1] == ps, (k, got[k][1], ps)
+        assert [c.key() for c in got[k][0]] == [c.key() for c in want], k
+        n_unmapped += ps is None
+        if want and all(len(c.ops) for c in want):
+            assert al.format_sam(k, f"r{k}", read, "I" * len(read)) == o.format_sam(f"r{k}", read, "I" * len(read), prealign=ps)
+    assert 0 < n_unmapped < len(reads)
+
+
+@pytest.mark.gpu
+def test_banded_kernel_wide_bands_and_long_targets():
+    """bands wider than one 64-row chunk, reads without seeds (full matrix), chunked scratch"""
+    import stitch_amd
+    rng = random.Random(5)
+    targets = [("a", rnd(rng, 3000)), ("b", rnd(rng, 1500))]
+    reads = [mutate(rng, targets[0][1][200:2600], 0.05, 0.04, 0.04), rnd(rng, 300), targets[1][1][100:1400], mutate(rng, targets[1][1], 0.1, 0.05, 0.05)]
+    os.environ["STITCH_PREALIGN_BYTES"] = str(3 << 20)
+    try:
+        for w in (3, 40, 200):
+            kw = dict(pre_align=True, pre_align_min_score=1, kmer_size=9, band_width=w)
+            al = stitch_amd.Builder(**kw).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in targets], device=0)
+            got = al.align(reads)
+            o = orc.Aligners(targets, **kw)
+            for k, read in enumerate(reads):
+                o.align(read)
+                assert got[k][1] == o.prealign_score(), (w, k)
+    finally:
+        del os.environ["STITCH_PREALIGN_BYTES"]
