@@ -96,7 +96,8 @@ long stitch_format_sam(stitch_ctx*, uint32_t read_idx, const char* head, const u
 /* Timing of the last stitch_align_batch on this ctx, measured with HIP events on the stream the kernels ran on:
  * fill_ms = sum over launches of the DP fill kernel, walk_ms = fix-up + traceback kernel, launches = number of
  * fill launches, cells = DP cells filled by them.  Used by bench.py for the roofline line. */
-typedef struct stitch_timing { double fill_ms, walk_ms, h2d_ms, d2h_ms, host_ms; uint64_t cells; uint32_t launches; uint32_t jobs; } stitch_timing;
+typedef struct stitch_timing { double fill_ms, walk_ms, h2d_ms, d2h_ms, host_ms; uint64_t cells; uint32_t launches; uint32_t jobs;
+                               double prealign_ms /* banded kernel */, prealign_host_ms /* seeds, backbone, band */; } stitch_timing;
 int stitch_last_timing(const stitch_ctx*, stitch_timing* out);
 
 const char* stitch_last_error(void);

@@ -8,8 +8,6 @@
 namespace stitch {
 
 namespace {
-constexpr size_t MAX_MATCHES = 65536;          // beyond this the pair is scored over the full matrix
-
 inline uint64_t kmer_hash(const uint8_t* p, uint32_t k) {      // FNV-1a; equality is always re-checked on the bytes
     uint64_t h = 1469598103934665603ull;
     for (uint32_t a = 0; a < k; ++a) { h ^= p[a]; h *= 1099511628211ull; }
@@ -17,39 +15,39 @@ inline uint64_t kmer_hash(const uint8_t* p, uint32_t k) {      // FNV-1a; equali
 }
 }  // namespace
 
-KmerIndex build_kmer_index(const uint8_t* t, uint32_t n, uint32_t k) {
+KmerIndex build_kmer_index(const uint8_t* contigs, const std::vector<Strand>& strands, uint32_t k) {
     KmerIndex ix; ix.k = k;
-    if (k == 0 || n < k) return ix;
-    const uint32_t cnt = n - k + 1;
-    std::vector<uint64_t> h(cnt);
-    for (uint32_t j = 0; j < cnt; ++j) h[j] = kmer_hash(t + j, k);
-    std::vector<uint32_t> ord(cnt); std::iota(ord.begin(), ord.end(), 0u);
-    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return h[a] != h[b] ? h[a] < h[b] : a < b; });
-    ix.key.resize(cnt); ix.pos.resize(cnt);
-    for (uint32_t a = 0; a < cnt; ++a) { ix.key[a] = h[ord[a]]; ix.pos[a] = ord[a]; }
+    if (k == 0) return ix;
+    struct E { uint64_t h; uint32_t s, p; };
+    std::vector<E> es;
+    for (uint32_t s = 0; s < strands.size(); ++s)
+        for (uint32_t j = 0; j + k <= strands[s].len; ++j) es.push_back(E{kmer_hash(contigs + strands[s].off + j, k), s, j});
+    std::sort(es.begin(), es.end(), [](const E& a, const E& b) { return a.h != b.h ? a.h < b.h : a.s != b.s ? a.s < b.s : a.p < b.p; });
+    ix.key.resize(es.size()); ix.strand.resize(es.size()); ix.pos.resize(es.size());
+    for (size_t a = 0; a < es.size(); ++a) { ix.key[a] = es[a].h; ix.strand[a] = es[a].s; ix.pos[a] = es[a].p; }
     return ix;
 }
 
-void make_band(const uint8_t* q, uint32_t m, const uint8_t* t, uint32_t n, const KmerIndex& ix, uint32_t w, int32_t match,
-               int32_t gap_open, int32_t gap_extend, std::vector<uint16_t>& lo, std::vector<uint16_t>& hi) {
+void find_seeds(const KmerIndex& ix, const uint8_t* contigs, const std::vector<Strand>& strands, const uint8_t* q, uint32_t m,
+                std::vector<std::vector<Seed>>& seeds) {
+    seeds.assign(strands.size(), {});
     const uint32_t k = ix.k;
-    lo.assign(n + 1, (uint16_t)(m + 1)); hi.assign(n + 1, 0);
-    auto full = [&]() { std::fill(lo.begin(), lo.end(), (uint16_t)0); std::fill(hi.begin(), hi.end(), (uint16_t)(m + 1)); };
-
-    // 1. exact k-mer matches, ordered by (query start, target start)
-    struct Seed { uint32_t i, j; };
-    std::vector<Seed> seeds;
-    if (k > 0 && m >= k && !ix.key.empty()) {
-        for (uint32_t i = 0; i + k <= m && seeds.size() <= MAX_MATCHES; ++i) {
-            const uint64_t h = kmer_hash(q + i, k);
-            auto a = std::lower_bound(ix.key.begin(), ix.key.end(), h);
-            for (; a != ix.key.end() && *a == h; ++a) {
-                const uint32_t j = ix.pos[(size_t)(a - ix.key.begin())];
-                if (memcmp(q + i, t + j, k) == 0) seeds.push_back(Seed{i, j});
-            }
+    if (k == 0 || m < k || ix.key.empty()) return;
+    for (uint32_t i = 0; i + k <= m; ++i) {
+        const uint64_t h = kmer_hash(q + i, k);
+        for (auto a = std::lower_bound(ix.key.begin(), ix.key.end(), h); a != ix.key.end() && *a == h; ++a) {
+            const size_t e = (size_t)(a - ix.key.begin());
+            const uint32_t s = ix.strand[e], j = ix.pos[e];
+            if (seeds[s].size() <= MAX_MATCHES && memcmp(q + i, contigs + strands[s].off + j, k) == 0) seeds[s].push_back(Seed{i, j});
         }
     }
-    if (seeds.empty() || seeds.size() > MAX_MATCHES) { full(); return; }
+}
+
+bool make_band(const std::vector<Seed>& seeds, uint32_t m, uint32_t n, uint32_t k, uint32_t w, int32_t match, int32_t gap_open,
+               int32_t gap_extend, std::vector<uint16_t>& lo, std::vector<uint16_t>& hi) {
+    lo.assign(n + 1, (uint16_t)(m + 1)); hi.assign(n + 1, 0);
+    // 1. no seeds, or too many: the band is the full matrix
+    if (seeds.empty() || seeds.size() > MAX_MATCHES) { std::fill(lo.begin(), lo.end(), (uint16_t)0); std::fill(hi.begin(), hi.end(), (uint16_t)(m + 1)); return true; }
 
     // 2. backbone: best-scoring chain of seeds (k * match per seed, + match for a seed that continues the one a step up the
     //    diagonal, gap penalty -gap_open - gap_extend * d for d = max(query gap, target gap) > 0); first best wins
@@ -80,15 +78,28 @@ void make_band(const uint8_t* q, uint32_t m, const uint8_t* t, uint32_t n, const
     for (int b = (int)end; b >= 0; b = from[b]) chain.push_back((uint32_t)b);
     std::reverse(chain.begin(), chain.end());
 
-    // 3. band around the backbone
+    // 3. band around the backbone: the union of the squares of half-width w around its points
     auto add = [&](long r, long c) {
         const long c0 = std::max<long>(c - (long)w, 0), c1 = std::min<long>(c + (long)w, (long)n);
         const uint16_t r0 = (uint16_t)std::max<long>(r - (long)w, 0), r1 = (uint16_t)(std::min<long>(r + (long)w, (long)m) + 1);
         for (long cc = c0; cc <= c1; ++cc) { if (r0 < lo[cc]) lo[cc] = r0; if (r1 > hi[cc]) hi[cc] = r1; }
     };
+    // the same for the points (r + t, c + t), t = 0..len, of a diagonal run, one update per column instead of one per point
+    // and column: column cc is within w of the points t in [cc - c - w, cc - c + w]
+    auto add_diag = [&](long r, long c, long len) {
+        if (len < 0) return;
+        const long c0 = std::max<long>(c - (long)w, 0), c1 = std::min<long>(c + len + (long)w, (long)n);
+        for (long cc = c0; cc <= c1; ++cc) {
+            const long t0 = std::max<long>(cc - c - (long)w, 0), t1 = std::min<long>(cc - c + (long)w, len);
+            if (t0 > t1) continue;
+            const uint16_t r0 = (uint16_t)std::max<long>(r + t0 - (long)w, 0), r1 = (uint16_t)(std::min<long>(r + t1 + (long)w, (long)m) + 1);
+            if (r0 < lo[cc]) lo[cc] = r0;
+            if (r1 > hi[cc]) hi[cc] = r1;
+        }
+    };
     for (size_t p = 0; p < chain.size(); ++p) {
         const Seed s = seeds[chain[p]];
-        for (uint32_t a = 0; a <= k; ++a) add((long)s.i + a, (long)s.j + a);
+        add_diag((long)s.i, (long)s.j, (long)k);
         if (p + 1 < chain.size()) {
             const Seed nx = seeds[chain[p + 1]];
             const long ai = (long)s.i + k, aj = (long)s.j + k;
@@ -98,9 +109,10 @@ void make_band(const uint8_t* q, uint32_t m, const uint8_t* t, uint32_t n, const
             }
         }
     }
-    { const Seed s = seeds[chain.front()]; for (long a = 1; a <= (long)std::min(s.i, s.j); ++a) add((long)s.i - a, (long)s.j - a); }
+    { const Seed s = seeds[chain.front()]; const long back = (long)std::min(s.i, s.j); add_diag((long)s.i - back, (long)s.j - back, back - 1); }
     { const Seed s = seeds[chain.back()]; const long ie = (long)s.i + k, je = (long)s.j + k;
-      for (long a = 1; a <= std::min((long)m - ie, (long)n - je); ++a) add(ie + a, je + a); }
+      add_diag(ie + 1, je + 1, std::min((long)m - ie, (long)n - je) - 1); }
+    return false;
 }
 
 }  // namespace stitch

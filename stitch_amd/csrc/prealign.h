@@ -11,17 +11,27 @@
 
 namespace stitch {
 
-// k-mers of one target strand: (hash, position) sorted, so that the positions of a k-mer come out ascending
+// k-mers of all target strands: (hash, strand, position) sorted, so that one lookup per read position yields the seeds of
+// every strand, each strand's in ascending position
 struct KmerIndex {
     uint32_t k = 0;
     std::vector<uint64_t> key;
-    std::vector<uint32_t> pos;
+    std::vector<uint32_t> strand, pos;
 };
-KmerIndex build_kmer_index(const uint8_t* t, uint32_t n, uint32_t k);
+struct Strand { uint64_t off; uint32_t len; };          // a target strand inside the context's contig buffer
+KmerIndex build_kmer_index(const uint8_t* contigs, const std::vector<Strand>& strands, uint32_t k);
 
-// rows [lo[c], hi[c]) of the DP matrix (rows 0..m = query prefix lengths) that belong to the band in column c = 0..n
-void make_band(const uint8_t* q, uint32_t m, const uint8_t* t, uint32_t n, const KmerIndex& idx, uint32_t w, int32_t match,
-               int32_t gap_open, int32_t gap_extend, std::vector<uint16_t>& lo, std::vector<uint16_t>& hi);
+// exact k-mer matches of read q against every strand, ordered by (read start, target start); a strand stops collecting
+// after MAX_MATCHES + 1 seeds (such a pair is scored over the full matrix)
+struct Seed { uint32_t i, j; };
+constexpr size_t MAX_MATCHES = 65536;
+void find_seeds(const KmerIndex& ix, const uint8_t* contigs, const std::vector<Strand>& strands, const uint8_t* q, uint32_t m,
+                std::vector<std::vector<Seed>>& seeds);
+
+// rows [lo[c], hi[c]) of the DP matrix (rows 0..m = read prefix lengths) that belong to the band in column c = 0..n
+// returns true when the band is the full matrix (no seeds, or more than MAX_MATCHES)
+bool make_band(const std::vector<Seed>& seeds, uint32_t m, uint32_t n, uint32_t k, uint32_t w, int32_t match, int32_t gap_open,
+               int32_t gap_extend, std::vector<uint16_t>& lo, std::vector<uint16_t>& hi);
 
 // one (read, target strand) pair of a banded launch; offsets are element offsets into the launch's device buffers
 struct BandPair {

@@ -24,10 +24,11 @@ __device__ __forceinline__ long long shfl_up_ll(long long v, int d) {
 __device__ __forceinline__ int32_t floor_min(long long v) { return v < (long long)MIN_SCORE ? MIN_SCORE : (int32_t)v; }
 }  // namespace
 
-__global__ __launch_bounds__(64) void banded_score_kernel(const BandPair* __restrict__ pairs, BandScoring sc, const uint8_t* __restrict__ reads,
-                                                          const uint8_t* __restrict__ contigs, const uint16_t* __restrict__ bands,
-                                                          int32_t* __restrict__ state, int32_t* __restrict__ scores) {
-    const BandPair P = pairs[blockIdx.x];
+__global__ __launch_bounds__(64) void banded_score_kernel(const BandPair* __restrict__ pairs, const uint32_t* __restrict__ which, BandScoring sc,
+                                                          const uint8_t* __restrict__ reads, const uint8_t* __restrict__ contigs,
+                                                          const uint16_t* __restrict__ bands, int32_t* __restrict__ state, int32_t* __restrict__ scores) {
+    const uint32_t pid = which[blockIdx.x];
+    const BandPair P = pairs[pid];
     const int lane = threadIdx.x;
     const uint32_t m = P.m, n = P.n;
     const uint8_t* q = reads + P.q_off; const uint8_t* t = contigs + P.t_off;
@@ -79,12 +80,156 @@ __global__ __launch_bounds__(64) void banded_score_kernel(const BandPair* __rest
     }
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) best = max(best, __shfl_xor(best, dd, 64));
-    if (lane == 0) scores[blockIdx.x] = best;
+    if (lane == 0) scores[pid] = best;
 }
 
-void launch_banded_scores(const BandPair* d_pairs, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
+// Pairs without a single k-mer match are scored over the FULL matrix (the band is everything): ~5 % of the pairs of a random
+// 10 kb read against 5 kb targets, 50 M cells each.  One workgroup per pair, H and D of all rows in LDS, the rows dealt in
+// contiguous slices to the threads: per column a thread (1) computes D and T = max(0, diagonal, D) of its rows and the
+// maximum of T - ge*i over them, (2) receives the maximum over the slices above it (workgroup scan), (3) finishes I and H.
+constexpr int FULL_THREADS = 256;
+constexpr uint32_t FULL_MAX_ROWS = 18000;             // 8 bytes of LDS per row
+__global__ __launch_bounds__(FULL_THREADS) void full_score_kernel(const BandPair* __restrict__ pairs, const uint32_t* __restrict__ which, BandScoring sc,
+                                                                   const uint8_t* __restrict__ reads, const uint8_t* __restrict__ contigs,
+                                                                   int32_t* __restrict__ scores) {
+    extern __shared__ int32_t lds[];
+    const uint32_t pid = which[blockIdx.x];
+    const BandPair P = pairs[pid];
+    const uint32_t m = P.m, n = P.n;
+    const uint8_t* q = reads + P.q_off; const uint8_t* t = contigs + P.t_off;
+    int32_t* H = lds; int32_t* D = lds + (m + 1);                       // H[i], D[i] of the previous column, rows 0..m
+    __shared__ long long part[FULL_THREADS];
+    __shared__ int32_t red[FULL_THREADS];
+    const int tid = threadIdx.x;
+    const uint32_t per = (m + FULL_THREADS - 1) / FULL_THREADS;
+    const uint32_t i0 = 1 + (uint32_t)tid * per, i1 = min(i0 + per, m + 1);          // rows [i0, i1)
+    const long long go = sc.gap_open, ge = sc.gap_extend;
+    for (uint32_t i = tid; i <= m; i += FULL_THREADS) { H[i] = 0; D[i] = MIN_SCORE; }    // column 0: H = 0 (free clipping), no deletion yet
+    __syncthreads();
+    int32_t best = 0;
+    for (uint32_t j = 1; j <= n; ++j) {
+        const uint8_t tj = t[j - 1];
+        int32_t diag = i0 <= m ? H[i0 - 1] : 0;                          // H(i0-1, j-1), read before anybody overwrites it
+        __syncthreads();
+        long long mx = NO_KEY;
+        for (uint32_t i = i0; i < i1; ++i) {
+            const int32_t hl = H[i];
+            const int32_t d = floor_min(max((long long)D[i] + ge, (long long)hl + go + ge));
+            const int32_t s = q[i - 1] == tj ? sc.match : sc.mismatch;
+            const int32_t T = max(max(floor_min((long long)diag + s), d), 0);
+            diag = hl;
+            D[i] = d; H[i] = T;                                           // H holds T until step 3
+            const long long key = (long long)T - ge * (long long)i;
+            mx = key > mx ? key : mx;
+        }
+        part[tid] = mx;
+        __syncthreads();
+        // exclusive maximum over the slices above (row 0, H = 0, is above everything: key 0)
+        long long carry = 0;
+        for (int u = 0; u < tid; ++u) { const long long v = part[u]; carry = v > carry ? v : carry; }
+        for (uint32_t i = i0; i < i1; ++i) {
+            const int32_t T = H[i];
+            const int32_t I = floor_min(carry + go + ge * (long long)i);
+            const int32_t h = max(T, I);
+            H[i] = h; best = max(best, h);
+            const long long key = (long long)T - ge * (long long)i;
+            carry = key > carry ? key : carry;
+        }
+        __syncthreads();
+    }
+    red[tid] = best;
+    __syncthreads();
+    for (int d = FULL_THREADS / 2; d >= 1; d >>= 1) { if (tid < d) red[tid] = max(red[tid], red[tid + d]); __syncthreads(); }
+    if (tid == 0) scores[pid] = red[0];
+}
+
+// The same with the rows in registers (PER rows per thread, m <= 256 * PER): no LDS traffic in the row loops, the scan of
+// the slices' maxima is a wave prefix maximum plus one LDS exchange between the four waves.
+template <int PER>
+__global__ __launch_bounds__(FULL_THREADS) void full_score_reg_kernel(const BandPair* __restrict__ pairs, const uint32_t* __restrict__ which, BandScoring sc,
+                                                                       const uint8_t* __restrict__ reads, const uint8_t* __restrict__ contigs,
+                                                                       int32_t* __restrict__ scores) {
+    const uint32_t pid = which[blockIdx.x];
+    const BandPair P = pairs[pid];
+    const uint32_t m = P.m, n = P.n;
+    const uint8_t* q = reads + P.q_off; const uint8_t* t = contigs + P.t_off;
+    __shared__ long long wave_tot[FULL_THREADS / 64];
+    __shared__ int32_t wave_last[2][FULL_THREADS / 64];      // H of a wave's last row, by column parity
+    __shared__ int32_t red[FULL_THREADS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t i0 = 1 + (uint32_t)tid * PER;
+    const long long go = sc.gap_open, ge = sc.gap_extend;
+    int32_t H[PER], D[PER]; uint8_t qb[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { H[u] = 0; D[u] = MIN_SCORE; qb[u] = i0 + u <= m ? q[i0 + u - 1] : 0; }
+    if (lane == 63) wave_last[0][wave] = 0;
+    __syncthreads();
+    int32_t best = 0;
+    for (uint32_t j = 1; j <= n; ++j) {
+        const uint8_t tj = t[j - 1];
+        // H(i0 - 1, j - 1): the last row of the thread before (row 0 for thread 0)
+        int32_t diag = __shfl_up(H[PER - 1], 1, 64);
+        if (lane == 0) diag = wave == 0 ? 0 : wave_last[(j - 1) & 1][wave - 1];
+        long long mx = NO_KEY;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const uint32_t i = i0 + u;
+            const int32_t hl = H[u];
+            const int32_t d = floor_min(max((long long)D[u] + ge, (long long)hl + go + ge));
+            const int32_t s = qb[u] == tj ? sc.match : sc.mismatch;
+            const int32_t T = max(max(floor_min((long long)diag + s), d), 0);
+            diag = hl;
+            if (i <= m) { D[u] = d; H[u] = T; const long long key = (long long)T - ge * (long long)i; mx = key > mx ? key : mx; }
+        }
+        long long incl = mx;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const long long o = shfl_up_ll(incl, dd); if (lane >= dd && o > incl) incl = o; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        long long carry = shfl_up_ll(incl, 1); if (lane == 0) carry = 0;            // row 0 (key 0) is above everything
+        if (carry < 0) carry = 0;
+        for (int w = 0; w < wave; ++w) { const long long v = wave_tot[w]; carry = v > carry ? v : carry; }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const uint32_t i = i0 + u;
+            if (i <= m) {
+                const int32_t T = H[u];
+                const int32_t I = floor_min(carry + go + ge * (long long)i);
+                const int32_t h = max(T, I);
+                H[u] = h; best = max(best, h);
+                const long long key = (long long)T - ge * (long long)i;
+                carry = key > carry ? key : carry;
+            }
+        }
+        if (lane == 63) wave_last[j & 1][wave] = H[PER - 1];
+        __syncthreads();
+    }
+    red[tid] = best;
+    __syncthreads();
+    for (int d = FULL_THREADS / 2; d >= 1; d >>= 1) { if (tid < d) red[tid] = max(red[tid], red[tid + d]); __syncthreads(); }
+    if (tid == 0) scores[pid] = red[0];
+}
+
+void launch_full_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_full, uint32_t max_m, const BandScoring& sc, const uint8_t* d_reads,
+                        const uint8_t* d_contigs, int32_t* d_scores, hipStream_t stream) {
+    if (!n_full) return;
+    const uint32_t per = (max_m + FULL_THREADS - 1) / FULL_THREADS;
+#define STITCH_FULL_REG(PER_) hipLaunchKernelGGL(full_score_reg_kernel<PER_>, dim3(n_full), dim3(FULL_THREADS), 0, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_scores)
+    if (per <= 8) { STITCH_FULL_REG(8); return; }
+    if (per <= 16) { STITCH_FULL_REG(16); return; }
+    if (per <= 24) { STITCH_FULL_REG(24); return; }
+    if (per <= 32) { STITCH_FULL_REG(32); return; }
+    if (per <= 40) { STITCH_FULL_REG(40); return; }
+#undef STITCH_FULL_REG
+    const size_t lds = 8ull * (max_m + 1);
+    (void)hipFuncSetAttribute((const void*)full_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(full_score_kernel, dim3(n_full), dim3(FULL_THREADS), lds, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_scores);
+}
+uint32_t full_score_max_rows() { return FULL_MAX_ROWS; }
+
+void launch_banded_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
                           const uint16_t* d_bands, int32_t* d_state, int32_t* d_scores, hipStream_t stream) {
-    if (n_pairs) hipLaunchKernelGGL(banded_score_kernel, dim3(n_pairs), dim3(64), 0, stream, d_pairs, sc, d_reads, d_contigs, d_bands, d_state, d_scores);
+    if (n_pairs) hipLaunchKernelGGL(banded_score_kernel, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_bands, d_state, d_scores);
 }
 
 }  // namespace stitch

@@ -17,6 +17,8 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 #include "../../include/stitch_gpu.h"
 #include "dp_core.h"
@@ -25,8 +27,11 @@
 #include "prealign.h"
 
 namespace stitch {
-void launch_banded_scores(const BandPair* d_pairs, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
+void launch_banded_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
                           const uint16_t* d_bands, int32_t* d_state, int32_t* d_scores, hipStream_t stream);
+void launch_full_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_full, uint32_t max_m, const BandScoring& sc, const uint8_t* d_reads,
+                        const uint8_t* d_contigs, int32_t* d_scores, hipStream_t stream);
+uint32_t full_score_max_rows();
 struct FillShared {
     const int32_t* S0; const uint32_t* Slen0; const int32_t* Sn0; const uint8_t* SnSet0; const uint8_t* Smove0;
     const uint32_t* lx0; const JumpBase* base0;
@@ -83,7 +88,7 @@ struct stitch_ctx {
     bool tm_fast = false;                        // last run_jobs used the Local-mode 16-bit kernel
     size_t mem_limit = 0;                        // optional cap on arena bytes (STITCH_ARENA_BYTES), for tests
     // banded pre-alignment filter (prealign.h): host copies of the contig strands, their k-mer indexes, device scratch
-    std::vector<uint8_t> h_xseq; std::vector<KmerIndex> kidx;
+    std::vector<uint8_t> h_xseq; std::vector<Strand> strands; KmerIndex kidx;
     uint8_t* pre_buf = nullptr; size_t pre_bytes = 0;
 };
 
@@ -259,7 +264,8 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     if (o->pre_align) {
         c->h_xseq = xseq;
-        for (uint32_t a = 0; a < C; ++a) c->kidx.push_back(build_kmer_index(c->h_xseq.data() + c->al[a].seqoff, c->al[a].m, (uint32_t)o->kmer_size));
+        for (uint32_t a = 0; a < C; ++a) c->strands.push_back(Strand{c->al[a].seqoff, c->al[a].m});
+        c->kidx = build_kmer_index(c->h_xseq.data(), c->strands, (uint32_t)o->kmer_size);
         c->pre_bytes = (size_t)1 << 30;
         if (const char* e = getenv("STITCH_PREALIGN_BYTES")) c->pre_bytes = std::max<size_t>((size_t)1 << 20, (size_t)strtoull(e, nullptr, 10));
         HIP_TRY(hipMalloc((void**)&c->pre_buf, c->pre_bytes));
@@ -369,7 +375,10 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
             g_min = std::max(1u, (tiles + 2047) / 2048);
             // at least 4 workgroups per read: measured best on cfg2 (64 reads x 4 beats 85 x 3 by 15 %: shorter columns per
             // workgroup, and 50 contigs still split evenly)
-            max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, 4u));
+            // (reads aligned to a few contigs only -- pre-alignment subsets, origin re-alignments -- get fewer workgroups each,
+            // about 250 tiles per workgroup, and more of them share a launch)
+            const uint32_t g_des = std::min(4u, std::max(1u, (tiles + 249u) / 250u));
+            max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, g_des));
             if (const char* g = getenv("STITCH_WG_PER_READ")) max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, (uint32_t)std::max(1, atoi(g))));
         }
         while (k1 < jobs.size() && used + lay[k1].bytes + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].bytes; ++k1; }
@@ -539,7 +548,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
             const size_t m = jobs[k1].y.size();
             if (m > 65534) return fail(STITCH_EINVAL, "pre_align: reads longer than 65534 bases are not supported");
             size_t need = al256(m);
-            for (uint32_t a = 0; a < C; ++a) need += al256(4ull * (c.al[a].m + 1)) + al256(12ull * (m + 1)) + sizeof(BandPair) + 4;
+            for (uint32_t a = 0; a < C; ++a) need += al256(4ull * (c.al[a].m + 1)) + al256(12ull * (m + 1)) + sizeof(BandPair) + 12;
             if (bytes + need + 4096 > c.pre_bytes) break;
             bytes += need; ++k1;
         }
@@ -547,36 +556,72 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         const size_t nj = k1 - k0, np = nj * C;
         std::vector<uint8_t> h_reads; std::vector<uint16_t> h_bands; std::vector<BandPair> pairs(np);
         size_t state_elems = 0;
-        std::vector<uint16_t> lo, hi;
+        std::vector<uint32_t> full_ids, banded_ids; uint32_t full_max_m = 0;
+        auto t_h0 = std::chrono::steady_clock::now();
+        // seeds, backbone and band of every pair: independent per read, so the reads are dealt to host threads
+        struct PerRead { std::vector<uint16_t> bands; std::vector<uint64_t> band_at; std::vector<uint8_t> full; };
+        std::vector<PerRead> pr(nj);
+        {
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({nj, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16}));
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                std::vector<uint16_t> lo_, hi_; std::vector<std::vector<Seed>> seeds_;
+                for (;;) {
+                    const size_t q = next.fetch_add(1); if (q >= nj) break;
+                    const Job& jb = jobs[k0 + q]; PerRead& R = pr[q];
+                    R.band_at.assign(C, 0); R.full.assign(C, 0);
+                    find_seeds(c.kidx, c.h_xseq.data(), c.strands, jb.y.data(), (uint32_t)jb.y.size(), seeds_);
+                    for (uint32_t a = 0; a < C; ++a) {
+                        const bool full = make_band(seeds_[a], (uint32_t)jb.y.size(), c.al[a].m, (uint32_t)c.opts.kmer_size, (uint32_t)c.opts.band_width,
+                                                    c.opts.match_score, c.opts.gap_open, c.opts.gap_extend, lo_, hi_);
+                        if (full && jb.y.size() <= full_score_max_rows()) { R.full[a] = 1; continue; }                 // LDS kernel: no band needed
+                        R.band_at[a] = R.bands.size();
+                        R.bands.insert(R.bands.end(), lo_.begin(), lo_.end()); R.bands.insert(R.bands.end(), hi_.begin(), hi_.end());
+                    }
+                }
+            };
+            std::vector<std::thread> pool; for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+            work(); for (auto& th : pool) th.join();
+        }
         for (size_t q = 0; q < nj; ++q) {
             const Job& jb = jobs[k0 + q];
-            const uint64_t q_off = h_reads.size();
+            const uint64_t q_off = h_reads.size(), b_off = h_bands.size();
             h_reads.insert(h_reads.end(), jb.y.begin(), jb.y.end());
+            h_bands.insert(h_bands.end(), pr[q].bands.begin(), pr[q].bands.end());
             for (uint32_t a = 0; a < C; ++a) {
                 const Aligner& A = c.al[a];
-                make_band(jb.y.data(), (uint32_t)jb.y.size(), c.h_xseq.data() + A.seqoff, A.m, c.kidx[a], (uint32_t)c.opts.band_width, c.opts.match_score,
-                          c.opts.gap_open, c.opts.gap_extend, lo, hi);
                 BandPair& P = pairs[q * C + a];
-                P.m = (uint32_t)jb.y.size(); P.n = A.m; P.q_off = q_off; P.t_off = A.seqoff;
-                P.band_off = h_bands.size(); h_bands.insert(h_bands.end(), lo.begin(), lo.end()); h_bands.insert(h_bands.end(), hi.begin(), hi.end());
+                P.m = (uint32_t)jb.y.size(); P.n = A.m; P.q_off = q_off; P.t_off = A.seqoff; P.band_off = 0; P.state_off = 0;
+                if (pr[q].full[a]) { full_ids.push_back((uint32_t)(q * C + a)); full_max_m = std::max(full_max_m, P.m); continue; }
+                banded_ids.push_back((uint32_t)(q * C + a));
+                P.band_off = b_off + pr[q].band_at[a];
                 P.state_off = state_elems; state_elems += 3ull * (P.m + 1);
             }
+            pr[q] = PerRead();
         }
         uint8_t* p = c.pre_buf;
         uint8_t* d_reads = p; p += al256(h_reads.size());
         uint16_t* d_bands = (uint16_t*)p; p += al256(h_bands.size() * 2);
         BandPair* d_pairs = (BandPair*)p; p += al256(np * sizeof(BandPair));
         int32_t* d_scores = (int32_t*)p; p += al256(np * 4);
+        uint32_t* d_full = (uint32_t*)p; p += al256(full_ids.size() * 4);
+        uint32_t* d_banded = (uint32_t*)p; p += al256(banded_ids.size() * 4);
         int32_t* d_state = (int32_t*)p; p += al256(state_elems * 4);
         if ((size_t)(p - c.pre_buf) > c.pre_bytes) return fail(STITCH_EINTERNAL, "pre-alignment scratch overflow");
+        c.tm.prealign_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
+        auto t_k0 = std::chrono::steady_clock::now();
         HIP_TRY(hipMemcpyAsync(d_reads, h_reads.data(), h_reads.size(), hipMemcpyHostToDevice, c.stream));
         HIP_TRY(hipMemcpyAsync(d_bands, h_bands.data(), h_bands.size() * 2, hipMemcpyHostToDevice, c.stream));
         HIP_TRY(hipMemcpyAsync(d_pairs, pairs.data(), np * sizeof(BandPair), hipMemcpyHostToDevice, c.stream));
-        launch_banded_scores(d_pairs, (uint32_t)np, sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream);
+        if (!full_ids.empty()) HIP_TRY(hipMemcpyAsync(d_full, full_ids.data(), full_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
+        if (!banded_ids.empty()) HIP_TRY(hipMemcpyAsync(d_banded, banded_ids.data(), banded_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
+        launch_banded_scores(d_pairs, d_banded, (uint32_t)banded_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream);
+        launch_full_scores(d_pairs, d_full, (uint32_t)full_ids.size(), full_max_m, sc, d_reads, c.d_xseq, d_scores, c.stream);
         HIP_TRY(hipGetLastError());
         std::vector<int32_t> sco(np);
         HIP_TRY(hipMemcpyAsync(sco.data(), d_scores, np * 4, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
+        c.tm.prealign_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_k0).count();
         for (size_t q = 0; q < nj; ++q) {
             Job& jb = jobs[k0 + q];
             std::vector<uint32_t> kept; int32_t best = 0; bool any = false;
