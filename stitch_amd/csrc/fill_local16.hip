@@ -164,6 +164,9 @@ struct WaveCol {                 // wave-uniform state of one contig's column
     int32_t thr;                 // max(vrun << 16, 1): an S word >= thr has score >= vrun and a non-zero length
     uint32_t m, roff, j, n;
     uint32_t q;
+#ifdef STITCH_PROFILE
+    uint32_t n_tiles = 0, n_merge = 0, n_c2 = 0;
+#endif
     int32_t upS, upT;            // carries (words): S[prev][i0-1] and S'[curr][i0-1]
     ScanEl carry;
 };
@@ -246,8 +249,46 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
         wc.carry = scan_combine(wc.carry, last);
         wc.carry.key += K.ge * (int32_t)TILE; wc.carry.q += (int32_t)TILE;          // relative to the next tile
     }
-    // phase C
+    // phase C.  The insertion candidate changes a cell only where it beats {diagonal, deletion} (c2 of row_phase_c_word) AND
+    // is not beaten by the jump (c5): with c2 and c5 both true the merged result is the jump again, exactly the (T, mvT) of
+    // phase A (c5 and c2 give JW.score > BI.score > bs2h.score, hence c3, hence T = JW; c6 is c4).  That happens only where
+    // the alignment really inserts: in almost every tile in no row of no lane.  A first pass therefore only carries the
+    // chain's key through the lane's rows (the "I extended" traceback bit needs it anyway) and tests c2 && !c5, which are
+    // comparisons of scores: word(bi, il) > bs2h <=> bi > score(bs2h) (bs2h's low half is all ones), and !c5 <=>
+    // bi >= score(JW).  A negative insertion score changes nothing either: the merged cell is then clipped to (0, x-prefix), and
+    // so is T (BI.score >= JW.score and > bs2.score make T negative too).  Only if some lane of the wave sees all three in
+    // some row does the wave redo the rows with the full merge.
     int32_t Fo[R]; uint32_t code[R]; uint32_t tk = 0;
+    bool merge = LASTCOL;                      // (the last column also stores the insertion values of every row)
+    if (!LASTCOL) {
+        int32_t rk = run.key; bool c2any = false;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const bool ext = rk >= el[u].key;
+            code[u] = (ext ? TBB_IEXT : 0u) | (ra[u].dext ? TBB_DEXT : 0u);
+            rk = ext ? rk : el[u].key;
+            const int32_t bi = rk + LK.giL + K.ge * u;
+            const int32_t biw = (int32_t)((uint32_t)bi << 16);                     // only looked at when 0 <= bi (<= 32767)
+            c2any |= bi >= 0 && biw > ra[u].bs2h && (biw | 0xFFFF) >= ra[u].JW;
+        }
+        merge = __ballot(c2any) != 0ull;
+#ifdef STITCH_PROFILE
+        wc.n_tiles += 1; wc.n_merge += merge ? 1u : 0u; wc.n_c2 += (uint32_t)__popcll(__ballot(c2any));
+#endif
+    }
+    if (!merge) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const uint32_t i = i0 + u;
+            const int32_t F = ra[u].T; const uint32_t mv = ra[u].mvT;
+            code[u] |= mv; Fo[u] = F;
+            if (!PARTIAL || i < m) tk = (uint32_t)F > tk ? (uint32_t)F : tk;
+            if (PARTIAL) {
+                if (i == m) { rm.F = F; rm.mv = mv; rm.bits = code[u] & (TBB_IEXT | TBB_DEXT); rm.BD = ra[u].BD; rm.DG = ra[u].DG; }
+                if (i > m) { Fo[u] = 0; ra[u].BD = word_make(-16384, 0); code[u] = 0; }
+            }
+        }
+    } else {
 #pragma unroll
     for (int u = 0; u < R; ++u) {
         const uint32_t i = i0 + u;
@@ -266,6 +307,7 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
         }
         if (LASTCOL) { if (!PARTIAL || i <= m) { const GPtrsCold& C = *V.cold; C.S[r + u] = word_score(F); C.Slen[r + u] = word_len(F); C.Ival[r + u] = bi; C.Ilen[r + u] = il; } }
         ROW_FENCE_C(u)
+    }
     }
     // Running records of the lane, updated per tile, not per row (rows ascend within a lane and across its tiles, so an equal
     // value never replaces an earlier one; after a contig's first tiles these branches are rarely taken):
@@ -638,6 +680,9 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
             gptr<const u32x4> psn; gptr<const uint8_t> pxn; rec_ptrs(rn, psn, pxn);
             process(e, piece, T, psn, pxn);
         }
+#ifdef STITCH_PROFILE
+        pf_sum[2] += (unsigned long long)wc.n_merge + ((unsigned long long)wc.n_tiles << 32);
+#endif
         PROF(3)
         __syncthreads();
         PROF(7)
@@ -680,6 +725,7 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
         }
     }
 #ifdef STITCH_PROFILE
+    if (lane == 0) { atomicAdd((unsigned long long*)(V.err + 4) + 120, pf_sum[2] >> 32); atomicAdd((unsigned long long*)(V.err + 4) + 121, pf_sum[2] & 0xFFFFFFFFull); }
     pf_sum[1] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8]
     if (lane == 0 && blockIdx.x == 0) { unsigned long long* o = (unsigned long long*)(V.err + 4) + wave * 8; for (int k = 0; k < 8; ++k) o[k] = pf_sum[k]; }
 #endif

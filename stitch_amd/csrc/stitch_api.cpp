@@ -480,8 +480,9 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
         c.tm.launches += 1; c.tm.jobs += nj;
         if (getenv("STITCH_PROFILE_DUMP") && fast) {
             unsigned long long pf[128]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[0].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
+            for (uint32_t q = 0; q < nj; ++q) { unsigned long long tm2[2]; HIP_TRY(hipMemcpy(tm2, (const uint8_t*)views[q].err + 16 + 120 * 8, 16, hipMemcpyDeviceToHost)); fprintf(stderr, "[prof] job %u: tiles=%llu merged=%llu (%.1f%%)\n", q, tm2[0], tm2[1], 100.0 * tm2[1] / (tm2[0] ? tm2[0] : 1)); }
             static const char* nm[8] = {"gather/loop", "select", "barrier1", "slot-setup", "tile", "finalize", "tile_wait", "barrier2"};
-            for (int w = 0; w < waves; ++w) { fprintf(stderr, "[prof] wave %d:", w); for (int k = 0; k < 8; ++k) { if (k == 1) fprintf(stderr, " simd=%u slot=%u cu=%u", (unsigned)((pf[w * 8 + 1] >> 4) & 3), (unsigned)(pf[w * 8 + 1] & 15), (unsigned)((pf[w * 8 + 1] >> 8) & 15)); else fprintf(stderr, " %s=%.1fM", nm[k], pf[w * 8 + k] / 1e6); } fprintf(stderr, "\n"); }
+            for (int w = 0; w < waves; ++w) { fprintf(stderr, "[prof] wave %d:", w); for (int k = 0; k < 8; ++k) { if (k == 2) fprintf(stderr, " tiles=%llu merged=%llu", pf[w * 8 + 2] >> 32, pf[w * 8 + 2] & 0xFFFFFFFFull); else if (k == 1) fprintf(stderr, " simd=%u slot=%u cu=%u", (unsigned)((pf[w * 8 + 1] >> 4) & 3), (unsigned)(pf[w * 8 + 1] & 15), (unsigned)((pf[w * 8 + 1] >> 8) & 15)); else fprintf(stderr, " %s=%.1fM", nm[k], pf[w * 8 + k] / 1e6); } fprintf(stderr, "\n"); }
         }
         if (fast) for (uint32_t q = 0; q < nj; ++q) {
             uint32_t e = 0; HIP_TRY(hipMemcpy(&e, views[q].err, 4, hipMemcpyDeviceToHost));
