@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64) void fixup_walk_kernel(const JobView* __restric
     if (!A.skip_fixup) for (uint32_t k = lane; k < V.nact; k += 64) fixup_contig(V, V.act[k]);
     __syncthreads();
     if (A.mode == 1) {
-        for (uint32_t k = lane; k < V.nact; k += 64) walk_from(V, V.act[k], A.hdr[k], A.ops + (size_t)k * A.ops_cap, A.ops_cap);
+        // traceback_all candidates: one chain per active contig, walked by walk_all_kernel (one wavefront each)
     } else {
         const uint32_t c = A.mode == 0 ? pick_primary(V) : A.from;
         ChainHdr H;
@@ -293,8 +293,21 @@ __global__ __launch_bounds__(64) void fixup_walk_kernel(const JobView* __restric
     }
 }
 
-void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, hipStream_t stream) {
+// mode 1 (--suboptimal): the walk from every active contig's end cell, one wavefront per (job, contig)
+__global__ __launch_bounds__(64) void walk_all_kernel(const JobView* __restrict__ jobs, const WalkArgs* __restrict__ args, uint32_t stride) {
+    const uint32_t job = blockIdx.x / stride, k = blockIdx.x % stride;
+    const JobView& V = jobs[job];
+    const WalkArgs A = args[job];
+    if (A.mode != 1 || k >= V.nact) return;
+    ChainHdr H;
+    WaveWalk ex; ex.lane = threadIdx.x;
+    walk_from_t(V, V.act[k], H, A.ops + (size_t)k * A.ops_cap, A.ops_cap, ex);
+    if (threadIdx.x == 0) A.hdr[k] = H;
+}
+
+void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, uint32_t max_nact_mode1, hipStream_t stream) {
     hipLaunchKernelGGL(fixup_walk_kernel, dim3(n_jobs), dim3(64), 0, stream, d_jobs, d_args);
+    if (max_nact_mode1) hipLaunchKernelGGL(walk_all_kernel, dim3(n_jobs * max_nact_mode1), dim3(64), 0, stream, d_jobs, d_args, max_nact_mode1);
 }
 
 }  // namespace stitch

@@ -37,7 +37,7 @@ struct FillShared {
     const uint32_t* lx0; const JumpBase* base0;
 };
 void launch_fill(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillShared& sh, hipStream_t stream);
-void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, hipStream_t stream);
+void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, uint32_t max_nact_mode1, hipStream_t stream);
 constexpr uint32_t TILE_ROWS = 512;   // 64 lanes x 8 rows (Local-mode kernel; the generic one uses 256): contig row blocks are padded to this
 void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, const FillShared& sh, hipStream_t stream);
 }  // namespace stitch
@@ -470,7 +470,9 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev[1], c.stream));
         if (getenv("STITCH_DEBUG")) { HIP_TRY(hipStreamSynchronize(c.stream)); fprintf(stderr, "[stitch] fill done (%u jobs, fast=%d)\n", nj, (int)fast); }
-        launch_fixup_walk(d_views, d_wargs, nj, c.stream);
+        uint32_t max_nact_mode1 = 0;
+        for (uint32_t q = 0; q < nj; ++q) if (jobs[k0 + q].mode == 1) max_nact_mode1 = std::max(max_nact_mode1, lay[k0 + q].nact);
+        launch_fixup_walk(d_views, d_wargs, nj, max_nact_mode1, c.stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev[2], c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
@@ -509,7 +511,7 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
                     Retry rt{}; rt.a.hdr = (ChainHdr*)big; rt.a.ops = (OpRec*)(big + align_up(sizeof(Retry), 256)); rt.a.ops_cap = H.n_ops;
                     rt.a.mode = 2; rt.a.from = H.end_contig_idx; rt.a.skip_fixup = 1;
                     HIP_TRY(hipMemcpy(big, &rt, sizeof(Retry), hipMemcpyHostToDevice));
-                    launch_fixup_walk(d_views + q, (const WalkArgs*)(big + offsetof(Retry, a)), 1, c.stream);
+                    launch_fixup_walk(d_views + q, (const WalkArgs*)(big + offsetof(Retry, a)), 1, 0, c.stream);
                     HIP_TRY(hipStreamSynchronize(c.stream));
                     HIP_TRY(hipMemcpy(&H, big, sizeof(ChainHdr), hipMemcpyDeviceToHost));
                     ops_src = big + align_up(sizeof(Retry), 256);
