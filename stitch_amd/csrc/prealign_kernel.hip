@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdlib>
 
 #include "dp_core.h"
 #include "prealign.h"
@@ -143,62 +144,69 @@ __global__ __launch_bounds__(FULL_THREADS) void full_score_kernel(const BandPair
     if (tid == 0) scores[pid] = red[0];
 }
 
-// The same with the rows in registers (PER rows per thread, m <= 256 * PER): no LDS traffic in the row loops, the scan of
-// the slices' maxima is a wave prefix maximum plus one LDS exchange between the four waves.
+// The same with the rows in registers (PER rows per thread, m <= 256 * PER) and 32-bit arithmetic: no LDS traffic in the
+// row loops, the scan of the slices' maxima is a wave prefix maximum plus one LDS exchange between the four waves.  In a
+// full local matrix H >= 0 everywhere, so D and I stay above go + ge*(m+1) and nothing needs clamping; the host only sends
+// pairs here whose scores and keys fit 31 bits (launch_full_scores).
 template <int PER>
 __global__ __launch_bounds__(FULL_THREADS) void full_score_reg_kernel(const BandPair* __restrict__ pairs, const uint32_t* __restrict__ which, BandScoring sc,
                                                                        const uint8_t* __restrict__ reads, const uint8_t* __restrict__ contigs,
                                                                        int32_t* __restrict__ scores) {
+    static_assert(PER % 4 == 0, "rows per thread");
     const uint32_t pid = which[blockIdx.x];
     const BandPair P = pairs[pid];
     const uint32_t m = P.m, n = P.n;
     const uint8_t* q = reads + P.q_off; const uint8_t* t = contigs + P.t_off;
-    __shared__ long long wave_tot[FULL_THREADS / 64];
+    __shared__ int32_t wave_tot[FULL_THREADS / 64];
     __shared__ int32_t wave_last[2][FULL_THREADS / 64];      // H of a wave's last row, by column parity
     __shared__ int32_t red[FULL_THREADS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t i0 = 1 + (uint32_t)tid * PER;
-    const long long go = sc.gap_open, ge = sc.gap_extend;
-    int32_t H[PER], D[PER]; uint8_t qb[PER];
+    const int32_t ge = sc.gap_extend, goe = sc.gap_open + sc.gap_extend;
+    int32_t H[PER], D[PER]; uint32_t qw[PER / 4];            // the thread's read bases, four per word (0 beyond the read: rows > m)
 #pragma unroll
-    for (int u = 0; u < PER; ++u) { H[u] = 0; D[u] = MIN_SCORE; qb[u] = i0 + u <= m ? q[i0 + u - 1] : 0; }
+    for (int u = 0; u < PER; ++u) { H[u] = 0; D[u] = MIN_SCORE / 2; }
+#pragma unroll
+    for (int v = 0; v < PER / 4; ++v) {
+        uint32_t w = 0;
+        for (int b = 0; b < 4; ++b) { const uint32_t i = i0 + 4 * v + b; w |= (uint32_t)(i <= m ? q[i - 1] : 0) << (8 * b); }
+        qw[v] = w;
+    }
+    const int32_t k0 = -ge * (int32_t)i0;                    // key(i) = T(i) - ge*i = T + k0 - ge*u
+    const int32_t c0 = goe + ge * ((int32_t)i0 - 1);         // I(i) = carry + go + ge*i = carry + c0 + ge*u
     if (lane == 63) wave_last[0][wave] = 0;
     __syncthreads();
     int32_t best = 0;
     for (uint32_t j = 1; j <= n; ++j) {
-        const uint8_t tj = t[j - 1];
-        // H(i0 - 1, j - 1): the last row of the thread before (row 0 for thread 0)
-        int32_t diag = __shfl_up(H[PER - 1], 1, 64);
+        const uint32_t tj = t[j - 1];
+        int32_t diag = __shfl_up(H[PER - 1], 1, 64);          // H(i0 - 1, j - 1): the last row of the thread before (row 0 for thread 0)
         if (lane == 0) diag = wave == 0 ? 0 : wave_last[(j - 1) & 1][wave - 1];
-        long long mx = NO_KEY;
+        int32_t mx = INT32_MIN;
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const uint32_t i = i0 + u;
             const int32_t hl = H[u];
-            const int32_t d = floor_min(max((long long)D[u] + ge, (long long)hl + go + ge));
-            const int32_t s = qb[u] == tj ? sc.match : sc.mismatch;
-            const int32_t T = max(max(floor_min((long long)diag + s), d), 0);
+            const int32_t d = max(D[u] + ge, hl + goe);
+            const int32_t s = ((qw[u >> 2] >> (8 * (u & 3))) & 0xFFu) == tj ? sc.match : sc.mismatch;
+            const int32_t T = max(max(diag + s, d), 0);
             diag = hl;
-            if (i <= m) { D[u] = d; H[u] = T; const long long key = (long long)T - ge * (long long)i; mx = key > mx ? key : mx; }
+            D[u] = d; H[u] = T;                                // rows beyond m compute harmless values: their q byte is 0 and nothing reads them
+            if (i0 + u <= m) mx = max(mx, T + (k0 - ge * u));
         }
-        long long incl = mx;
+        int32_t incl = mx;
 #pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) { const long long o = shfl_up_ll(incl, dd); if (lane >= dd && o > incl) incl = o; }
+        for (int dd = 1; dd < 64; dd <<= 1) { const int32_t o = __shfl_up(incl, dd, 64); if (lane >= dd) incl = max(incl, o); }
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
-        long long carry = shfl_up_ll(incl, 1); if (lane == 0) carry = 0;            // row 0 (key 0) is above everything
-        if (carry < 0) carry = 0;
-        for (int w = 0; w < wave; ++w) { const long long v = wave_tot[w]; carry = v > carry ? v : carry; }
+        int32_t carry = __shfl_up(incl, 1, 64); if (lane == 0) carry = 0;        // row 0 (key 0) is above everything
+        carry = max(carry, 0);
+        for (int w = 0; w < wave; ++w) carry = max(carry, wave_tot[w]);
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const uint32_t i = i0 + u;
-            if (i <= m) {
+            if (i0 + u <= m) {
                 const int32_t T = H[u];
-                const int32_t I = floor_min(carry + go + ge * (long long)i);
-                const int32_t h = max(T, I);
+                const int32_t h = max(T, carry + (c0 + ge * u));
                 H[u] = h; best = max(best, h);
-                const long long key = (long long)T - ge * (long long)i;
-                carry = key > carry ? key : carry;
+                carry = max(carry, T + (k0 - ge * u));
             }
         }
         if (lane == 63) wave_last[j & 1][wave] = H[PER - 1];
@@ -214,12 +222,16 @@ void launch_full_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32
                         const uint8_t* d_contigs, int32_t* d_scores, hipStream_t stream) {
     if (!n_full) return;
     const uint32_t per = (max_m + FULL_THREADS - 1) / FULL_THREADS;
+    // the register kernel works in 32 bits: scores up to match * m and keys up to |ge| * (m + 1) must fit
+    const long long big = (long long)1 << 29;
+    const bool small = (long long)std::abs(sc.match) * (max_m + 1) < big && (long long)std::abs(sc.gap_extend) * (max_m + 2) + std::abs(sc.gap_open) < big &&
+                       std::abs((long long)sc.mismatch) < big;
 #define STITCH_FULL_REG(PER_) hipLaunchKernelGGL(full_score_reg_kernel<PER_>, dim3(n_full), dim3(FULL_THREADS), 0, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_scores)
-    if (per <= 8) { STITCH_FULL_REG(8); return; }
-    if (per <= 16) { STITCH_FULL_REG(16); return; }
-    if (per <= 24) { STITCH_FULL_REG(24); return; }
-    if (per <= 32) { STITCH_FULL_REG(32); return; }
-    if (per <= 40) { STITCH_FULL_REG(40); return; }
+    if (small && per <= 8) { STITCH_FULL_REG(8); return; }
+    if (small && per <= 16) { STITCH_FULL_REG(16); return; }
+    if (small && per <= 24) { STITCH_FULL_REG(24); return; }
+    if (small && per <= 32) { STITCH_FULL_REG(32); return; }
+    if (small && per <= 40) { STITCH_FULL_REG(40); return; }
 #undef STITCH_FULL_REG
     const size_t lds = 8ull * (max_m + 1);
     (void)hipFuncSetAttribute((const void*)full_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

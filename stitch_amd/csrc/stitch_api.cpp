@@ -266,7 +266,7 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
         c->h_xseq = xseq;
         for (uint32_t a = 0; a < C; ++a) c->strands.push_back(Strand{c->al[a].seqoff, c->al[a].m});
         c->kidx = build_kmer_index(c->h_xseq.data(), c->strands, (uint32_t)o->kmer_size);
-        c->pre_bytes = (size_t)1 << 30;
+        c->pre_bytes = (size_t)4 << 30;                       // 256 reads x 100 target strands of cfg3 per launch
         if (const char* e = getenv("STITCH_PREALIGN_BYTES")) c->pre_bytes = std::max<size_t>((size_t)1 << 20, (size_t)strtoull(e, nullptr, 10));
         HIP_TRY(hipMalloc((void**)&c->pre_buf, c->pre_bytes));
     }
