@@ -3,16 +3,19 @@
 // Same recurrence, tie-breaks and results as fill_kernel.hip (and therefore as
 // fg-stitch-lib/src/align/aligners/single_contig_aligner.rs:188-451 + multi_contig_aligner.rs:264-347), with the
 // simplifications Local mode allows and an HBM-leaner, VALU-leaner inner loop:
-//   * move selection by ordered integer keys (dp_core.h, row_phase_a_key): the reference's chain of `>` tests
-//     becomes a handful of max operations, and the winning priority is the traceback move code;
-//   * row state is 8 bytes (S<<16 | S.len, D<<16 | D.len) instead of 16, read and written as 16-byte vectors;
-//   * 4 rows per lane (256-row tiles; 8 is a build option), 12 waves per workgroup so that three waves share a SIMD;
-//     full tiles run a check-free instance, only a contig's last tile handles ragged ends and row m;
-//   * the next tile's state is prefetched into registers while the current one is computed;
-//   * the insertion scan and the neighbour hand-offs use DPP row shifts / broadcasts instead of LDS permutes;
+//   * a candidate is one signed word score<<16 | len (dp_core.h, row_phase_a_word): the reference's chain of `>` tests
+//     with length tie-breaks becomes compares and selects on words;
+//   * row state is 8 bytes (S word, D word) instead of 16, read and written as 16-byte vectors;
+//   * 4 rows per lane (256-row tiles), 12 waves per workgroup so that three waves share a SIMD; the waves share the
+//     workgroup's tiles (slot table in LDS, carries handed from wave to wave through LDS), full tiles run a check-free
+//     instance, only a contig's last tile handles ragged ends and row m, and the last column is an instance of its own;
+//   * the next tile's state is loaded into the current tile's registers right after their last use (one buffer);
+//   * the insertion scan is a lane-tagged max on DPP row shifts / broadcasts; the insertion is merged into a cell only
+//     in tiles where it can change one;
 //   * the y-suffix trackers Sn/Ly (:431-447) are only touched for cells that reach the contig's running maximum —
-//     in Local mode only rows whose Sn equals the contig's final maximum can influence the result;
-//   * the per-contig jump selection (multi_contig_aligner.rs:292-331) is done by the wave that owns the contig, with
+//     in Local mode only rows whose Sn equals the contig's final maximum can influence the result — and
+//     written as packed records without reading Sn back;
+//   * the per-contig jump selection (multi_contig_aligner.rs:292-331) is done by the wave that starts the contig, with
 //     the other contigs' column arg-max spread over its lanes (one barrier per column, two with several workgroups).
 // Eligibility is decided on the host (stitch_api.cpp: local16_ok): mode local, go + ge < 0, match * n <= 32767,
 // n + max contig length < 65535, penalties >= -16000.  Anything else runs the generic int32 kernel.
@@ -60,10 +63,11 @@ struct GPtrs {                // hot pointers, kept in registers
 
 // Software pipeline of the tile loop.  hipcc cannot count vmcnt across this loop (conditional memory operations in the body
 // make it fall back to vmcnt(0), which also waits for the prefetch it has just issued), so the state prefetch is issued and
-// waited for by hand (cdna_hip_programming.md §5.7): loads of the NEXT tile are issued right after the wait for the current
-// one; when they are needed the only younger vector-memory operations that must be allowed to stay in flight are the 5
-// stores of the tile computed in between (4 x 16 B state + 8 B traceback), hence vmcnt(5).  Extra (conditional) operations
-// only make the wait stricter.
+// waited for by hand (cdna_hip_programming.md §5.7): the loads of the NEXT slot are issued inside the current tile, right
+// after phase A has consumed the registers they land in; when they are needed, at the top of the next slot, the only
+// younger vector-memory operations that may still be in flight are the stores of the tile computed in between (two 16-byte
+// state vectors and the traceback word at 4 rows per lane), hence vmcnt(3).  Extra (conditional) operations only make the
+// wait stricter.
 #ifndef STITCH_R
 #define STITCH_R 4
 #endif
@@ -140,18 +144,8 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 
 // Rows of a tile are independent, and the scheduler would interleave all eight of them: dozens of compare masks (SGPR
 // pairs) live at once, far beyond the 102 SGPRs of a wave, i.e. v_writelane/v_readlane spill traffic in the inner loop.
-// At two waves per SIMD a wave only gets every other issue slot anyway, so nothing is lost by finishing one row before the
-// next: the fence keeps the schedule row-serial.
-#if defined(STITCH_PAIR_FENCE_A)
-#define ROW_FENCE_A(u) if ((u) & 1) __builtin_amdgcn_sched_barrier(0);
-#else
-#define ROW_FENCE_A(u) ROW_FENCE
-#endif
-#if defined(STITCH_PAIR_FENCE_C)
-#define ROW_FENCE_C(u) if ((u) & 1) __builtin_amdgcn_sched_barrier(0);
-#else
-#define ROW_FENCE_C(u) ROW_FENCE
-#endif
+// With three waves per SIMD nothing is lost by finishing one row before the next (measured: no difference without the
+// fence, with pairs of rows or row by row): the fence keeps the schedule row-serial.
 #ifndef STITCH_NO_ROW_FENCE
 #define ROW_FENCE __builtin_amdgcn_sched_barrier(0);
 #else
@@ -214,7 +208,7 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
     for (int u = 0; u < R; ++u) {
         const bool row1 = (u == 0) && (i0 == 1);
         row_phase_a_word(xb[u] == wc.q ? K.MW : K.XW, K.GE1, K.GO1, row1 ? wc.JSW1 : wc.JSW, u == 0 ? nS : Sp[u - 1], Sp[u], Dp[u], ra[u]);
-        ROW_FENCE_A(u)
+        ROW_FENCE
     }
     // The previous column's words are dead from here on: the NEXT slot's state is loaded into the same registers and lands
     // during phases B and C (one register buffer; the wait is at the top of the next slot).
@@ -306,7 +300,7 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
             if (i > m) { Fo[u] = 0; ra[u].BD = word_make(-16384, 0); code[u] = 0; }
         }
         if (LASTCOL) { if (!PARTIAL || i <= m) { const GPtrsCold& C = *V.cold; C.S[r + u] = word_score(F); C.Slen[r + u] = word_len(F); C.Ival[r + u] = bi; C.Ilen[r + u] = il; } }
-        ROW_FENCE_C(u)
+        ROW_FENCE
     }
     }
     // Running records of the lane, updated per tile, not per row (rows ascend within a lane and across its tiles, so an equal
