@@ -183,6 +183,19 @@ def test_multi_tile_contigs_and_long_reads():
     run_pair(targets, reads[:4], double_strand=True, suboptimal=True)
 
 
+@pytest.mark.parametrize("batch", [1, 3, 40])
+def test_ragged_contig_lengths_and_wave_ranges(batch):
+    """contigs of 1 row to several tiles in one database: tile ranges of waves and workgroups with empty, single-tile
+    and split contigs, for one read alone (many workgroups per read), a few, and a launch full of reads"""
+    rng = random.Random(11 + batch)
+    lens = [1, 2, 3, 255, 256, 257, 511, 513, 40, 1300, 7, 64]
+    targets = [(f"c{k}", rand_seq(rng, n)) for k, n in enumerate(lens)]
+    reads = [chimera(rng, [t for t in targets if len(t[1]) > 30], rng.randint(30, 500), both=True) for _ in range(batch)]
+    run_pair(targets, reads, double_strand=True, check_sam=False)
+    run_pair(targets[:4], reads[:2], check_sam=False)                      # a workgroup with fewer tiles than waves
+    run_pair(targets, reads[:3], circular=True, suboptimal=True, check_sam=False)
+
+
 def test_circular_realignment():
     """reads that wrap around the origin of circular contigs (realign_origin, aligners/mod.rs:442-553)"""
     rng = random.Random(3)
