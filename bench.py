@@ -157,10 +157,13 @@ def main():
             # cells (the DP cost is linear in read length).
             pre = args.cpu_prefix if args.cpu_prefix > 0 else args.read_len
             sample = [r[:pre] for r in reads[:args.cpu_reads]]
-            secs, ccells, _ = orc.cpu_bench([(n, s) for n, s in db], sample, threads=args.cpu_threads)
+            secs, ccells, cscores = orc.cpu_bench([(n, s) for n, s in db], sample, threads=args.cpu_threads)
+            # the same sample through the HIP path: the two sides must agree (parity proper is tests/, this is a run-time cross-check)
+            gres = aligners.align(sample)
+            same = all(len(g[0]) > 0 and g[0][0].score == int(cscores[k]) for k, g in enumerate(gres))
             cells_per_read = args.read_len * args.contigs * args.contig_len
             out["cpu_baseline"] = {"value": ccells / secs / cells_per_read, "unit": "reads/s", "cores": args.cpu_threads, "kind": "port",
-                                   "gcells_per_sec": ccells / secs / 1e9,
+                                   "gcells_per_sec": ccells / secs / 1e9, "gpu_scores_equal_on_sample": bool(same),
                                    "sample": f"first {pre} bp of the first {len(sample)} read(s) vs the full DB: {ccells} cells in {secs:.1f} s on "
                                              f"{args.cpu_threads} thread(s); reads/s = cells/s / {cells_per_read} cells per {args.read_len} bp read; C++ "
                                              f"restatement of fulcrumgenomics/stitch with its 16-byte row-major traceback cells "
