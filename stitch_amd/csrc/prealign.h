@@ -6,6 +6,7 @@
 // them.  The host finds the k-mer matches and the backbone and rasterises the band (this file); the banded DP itself runs
 // on the GPU (prealign_kernel.hip).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
