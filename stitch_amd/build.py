@@ -27,6 +27,7 @@ def build(force=False, verbose=False):
           [os.path.join(CSRC, f) for f in SOURCES]
     for d in os.environ.get("STITCH_DEFINES", "").split():
         cmd.append("-D" + d)                    # experiments only
+    cmd += os.environ.get("STITCH_HIPCC_FLAGS", "").split()          # experiments only
     if os.environ.get("STITCH_PROFILE_BUILD"):
         cmd.append("-DSTITCH_PROFILE")          # diagnostic build with in-kernel stamps (never shipped)
     if verbose:
