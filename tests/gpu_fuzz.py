@@ -1,0 +1,38 @@
+"""GPU fuzz of the Local kernel's multi-tile paths (and the pre-alignment filter) against the oracle.  Not collected by pytest:
+run `FUZZ_SECONDS=600 FUZZ_SEED=1000 python tests/gpu_fuzz.py` on a GPU box (round 1: 2051 cases, seeds 1000-3050, all equal)."""
+import os, random, sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import stitch_amd
+from oracle import oracle as orc
+from test_gpu_parity import chimera, rand_seq
+t_end = time.time() + float(os.environ.get("FUZZ_SECONDS", "600"))
+seed0 = int(os.environ.get("FUZZ_SEED", "1000"))
+n_ok = 0; seed = seed0
+while time.time() < t_end:
+    rng = random.Random(seed); seed += 1
+    T = rng.randint(1, 9)
+    lens = [rng.choice([rng.randint(1, 40), rng.randint(200, 700), rng.randint(700, 2600)]) for _ in range(T)]
+    targets = [(f"t{k}", rand_seq(rng, n)) for k, n in enumerate(lens)]
+    double = rng.random() < 0.4
+    opts = dict(double_strand=double, circular=rng.random() < 0.3, suboptimal=rng.random() < 0.25)
+    if rng.random() < 0.4:
+        opts.update(match_score=rng.choice([1, 2]), mismatch_score=rng.choice([-1, -4, -6]), gap_open=rng.choice([-6, -3, 0]), gap_extend=rng.choice([-2, -1]),
+                    default_jump_score=rng.choice([-10, -5, -1]))
+    if rng.random() < 0.2:
+        opts.update(pre_align=True, pre_align_min_score=rng.choice([20, 60]), kmer_size=rng.choice([8, 11]), band_width=rng.choice([5, 30]))
+    nreads = rng.choice([1, 2, 5, 30])
+    big = [t for t in targets if len(t[1]) > 30] or targets
+    reads = [chimera(rng, big, rng.randint(20, rng.choice([200, 900, 1600])), err=rng.choice([0.02, 0.08]), both=double) for _ in range(nreads)]
+    oo = {{"match_score": "match", "mismatch_score": "mismatch", "default_jump_score": "jump_score"}.get(k, k): v for k, v in opts.items()}
+    al = stitch_amd.Builder(**opts).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in targets])
+    o = orc.Aligners(targets, **oo)
+    res = al.align(reads)
+    for k, read in enumerate(reads[:6]):
+        want = o.align(read)
+        assert [c.key() for c in res[k][0]] == [c.key() for c in want], (seed - 1, k, opts, lens, len(read))
+        if opts.get("pre_align"):
+            assert res[k][1] == o.prealign_score(), (seed - 1, k)
+    n_ok += 1
+    if n_ok % 10 == 0:
+        print("cases ok:", n_ok, "last seed", seed - 1, flush=True)
+print("DONE cases ok:", n_ok, "seeds", seed0, "..", seed - 1, flush=True)
