@@ -130,8 +130,10 @@ STITCH_HD void fixup_contig(const JobView& V, uint32_t c) {
     SCell c0; c0.tb = r0.Smove; c0.len = r0.Slen; c0.idx = c; c0.from = 0;   // cell(0,n).S
     uint32_t* LxN = &V.Lx[(size_t)c * (n + 1) + n];
 
-    auto Sget = [&](uint32_t i) -> int32_t { return i == 0 ? S0 : V.S[roff + i - 1]; };
-    auto Sset = [&](uint32_t i, int32_t v) { if (i == 0) S0 = v; else V.S[roff + i - 1] = v; };
+    // S[curr][.]: row 0 and row m live in registers (row m is written through to memory), the other rows are loaded a block
+    // at a time (independent loads) and handed to the row bodies below as `cur`; for i == m `cur` IS the row-m register.
+    int32_t Sm_reg = V.S[roff + m - 1];
+    auto Sstore = [&](uint32_t i, int32_t v) { if (i >= 1) V.S[roff + i - 1] = v; };
     auto cell = [&](uint32_t i) -> SCell {
         if (i == 0) return c0;
         uint32_t r = roff + i - 1; SCell s; s.len = V.Slen[r];
@@ -145,17 +147,18 @@ STITCH_HD void fixup_contig(const JobView& V, uint32_t c) {
         V.SmoveF[r] = (uint8_t)tb; V.Slen[r] = len; V.SidxF[r] = idx; V.SfromF[r] = from;
     };
 
-    for (uint32_t i = 0; i <= m; ++i) {
+    constexpr uint32_t BLK = 8;
+    // pass 1, one row (:458-517).  `cur` = S[curr][i]
+    auto row1 = [&](uint32_t i, int32_t& cur, int32_t sn) {
         // (a) jump over the remaining bases of x (:460-466)
-        if (Sget(i) + P.jump_same > Sget(m)) {
-            Sset(m, Sget(i) + P.jump_same);
+        if (cur + P.jump_same > Sm_reg) {
+            Sm_reg = cur + P.jump_same; Sstore(m, Sm_reg);
             SCell ps = cell(i);
             cell_set(m, TB_XJUMP, ps.len, ps.idx, i);
         }
         // (b) y suffix clip (:469-491); the equal branch compares a cell's length with itself
-        int32_t sn = i == 0 ? sn0 : V.Sn[roff + i - 1];
-        if (sn > Sget(i)) {
-            Sset(i, sn);
+        if (sn > cur) {
+            cur = sn; Sstore(i, sn);
             uint32_t ly = i == 0 ? ly0 : V.Ly[roff + i - 1];
             uint32_t len = i == 0 ? (n - ly == 0 ? 0u : row0_at(P, n - ly, n).Slen) : V.SnLen[roff + i - 1];
             (void)ly;
@@ -163,38 +166,61 @@ STITCH_HD void fixup_contig(const JobView& V, uint32_t c) {
         }
         // (c) x suffix clip (:494-516)
         {
-            int32_t v = Sget(i) + P.xclip_suffix;
+            int32_t v = cur + P.xclip_suffix;
             bool do_x = false;
-            if (v > Sget(m)) do_x = true;
-            else if (v == Sget(m)) do_x = cell(i).len > cell(m).len;
+            if (v > Sm_reg) do_x = true;
+            else if (v == Sm_reg) do_x = cell(i).len > cell(m).len;
             if (do_x) {
-                Sset(m, v);
+                Sm_reg = v; Sstore(m, v);
                 *LxN = m - i;
                 SCell ps = cell(i);
                 cell_set(m, TB_XCLIP_SUFFIX, ps.len, ps.idx, i);
             }
         }
+    };
+    row1(0, S0, sn0);
+    for (uint32_t b0 = 1; b0 <= m; b0 += BLK) {
+        int32_t Sb[BLK], Snb[BLK];
+#pragma unroll
+        for (uint32_t k = 0; k < BLK; ++k) { const uint32_t i = b0 + k; Sb[k] = i <= m ? V.S[roff + i - 1] : 0; Snb[k] = i <= m ? V.Sn[roff + i - 1] : 0; }
+#pragma unroll
+        for (uint32_t k = 0; k < BLK; ++k) {
+            const uint32_t i = b0 + k;
+            if (i < m) row1(i, Sb[k], Snb[k]); else if (i == m) row1(i, Sm_reg, Snb[k]);
+        }
     }
-    for (uint32_t i = 1; i <= m; ++i) {                  // :521-554
+    // pass 2, one row (:521-554).  `above` = S[curr][i-1] after its own update, `cur` = S[curr][i], `ival` = I[curr][i]
+    auto row2 = [&](uint32_t i, int32_t above, int32_t& cur, int32_t ival) {
         uint32_t r = roff + i - 1;
-        int32_t i_score = Sget(i - 1) + P.gap_open + P.gap_extend;
-        if (i_score > V.Ival[r]) {
+        int32_t i_score = above + P.gap_open + P.gap_extend;
+        if (i_score > ival) {
             V.Ival[r] = i_score;
             SCell sv = cell(i - 1);
             V.ImoveF[r] = (uint8_t)sv.tb; V.Ilen[r] = sv.len + 1;
         }
-        if (i_score > Sget(i)) {
-            Sset(i, i_score);
+        if (i_score > cur) {
+            cur = i_score; Sstore(i, i_score);
             uint32_t prev_len = V.Ilen[r];
             cell_set(i, TB_INS, prev_len, c, i - 1);
-            if (Sget(i) + P.xclip_suffix > Sget(m)) {
-                Sset(m, Sget(i) + P.xclip_suffix);
+            if (cur + P.xclip_suffix > Sm_reg) {
+                Sm_reg = cur + P.xclip_suffix; Sstore(m, Sm_reg);
                 *LxN = m - i;
                 cell_set(m, TB_XCLIP_SUFFIX, prev_len, c, i);
             }
         }
+    };
+    int32_t above = S0;
+    for (uint32_t b0 = 1; b0 <= m; b0 += BLK) {
+        int32_t Sb[BLK], Ib[BLK];
+#pragma unroll
+        for (uint32_t k = 0; k < BLK; ++k) { const uint32_t i = b0 + k; Sb[k] = i <= m ? V.S[roff + i - 1] : 0; Ib[k] = i <= m ? V.Ival[roff + i - 1] : 0; }
+#pragma unroll
+        for (uint32_t k = 0; k < BLK; ++k) {
+            const uint32_t i = b0 + k;
+            if (i < m) { row2(i, above, Sb[k], Ib[k]); above = Sb[k]; } else if (i == m) { row2(i, above, Sm_reg, Ib[k]); above = Sm_reg; }
+        }
     }
-    V.Sm[c] = Sget(m);
+    V.Sm[c] = Sm_reg;
     V.Lm[c] = cell(m).len;
 }
 
