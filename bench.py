@@ -126,6 +126,7 @@ def main():
                        "reads_per_step_per_gpu": R, "cells_per_read": args.read_len * args.contigs * args.contig_len,
                        "scoring": "A=1 B=-4 O=-6 E=-2 J=-10", "sharding": "reads by rank, index broadcast once"},
             "gcells_per_sec": cells_all / dt / 1e9,
+            "device": (lambda p: {"name": p.name, "cus": p.multi_processor_count, "hbm_gib": round(p.total_memory / 2**30)})(torch.cuda.get_device_properties(local_rank)),
             "mapped_fraction": mapped / float(R * args.steps),
             "roofline": {"bound": "hbm", "kernel": "stitch::fill_local16_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
