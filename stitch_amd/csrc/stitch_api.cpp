@@ -337,7 +337,26 @@ int pick_waves(uint32_t nact, int maxw) {          // fewest rounds of contigs p
     return best_w;
 }
 
+static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs);
+
+// Jobs of one launch run side by side until the longest is done, so launches are formed from jobs of similar size: the list
+// is processed in descending order of work (read length x active rows) and handed back in the caller's order.
 int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
+    if (jobs.size() < 2) return run_jobs_in_order(c, jobs);
+    std::vector<size_t> perm(jobs.size());
+    for (size_t k = 0; k < perm.size(); ++k) perm[k] = k;
+    auto work = [&](const Job& jb) { unsigned long long rows = 0; for (uint32_t a : jb.act) rows += c.al[a].m; return rows * (unsigned long long)jb.y.size(); };
+    std::vector<unsigned long long> w(jobs.size());
+    for (size_t k = 0; k < jobs.size(); ++k) w[k] = work(jobs[k]);
+    std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return w[a] > w[b]; });
+    std::vector<Job> sorted; sorted.reserve(jobs.size());
+    for (size_t k : perm) sorted.push_back(std::move(jobs[k]));
+    const int rc = run_jobs_in_order(c, sorted);
+    for (size_t k = 0; k < perm.size(); ++k) jobs[perm[k]] = std::move(sorted[k]);
+    return rc;
+}
+
+static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     if (jobs.empty()) return STITCH_OK;
     HIP_TRY(hipSetDevice(c.device));
     std::vector<JobLayout> lay(jobs.size());
