@@ -196,6 +196,22 @@ def test_ragged_contig_lengths_and_wave_ranges(batch):
     run_pair(targets, reads[:3], circular=True, suboptimal=True, check_sam=False)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_scoring_at_the_limits_of_the_16_bit_kernel(seed):
+    """penalties down to -16000 and match scores up to 100 with reads as long as match * n <= 32767 allows (local16_ok)"""
+    rng = random.Random(5000 + seed)
+    targets = [(f"t{k}", rand_seq(rng, rng.choice([30, 300, 900]))) for k in range(rng.randint(1, 5))]
+    match = rng.choice([1, 7, 100])
+    opts = dict(match_score=match, mismatch_score=rng.choice([-1, -16000, -300]), gap_open=rng.choice([0, -8000, -1]),
+                gap_extend=rng.choice([-8000, -1, -16000]), default_jump_score=rng.choice([0, -16000, -5]),
+                double_strand=rng.random() < 0.5, circular=rng.random() < 0.3)
+    if opts["gap_open"] + opts["gap_extend"] < -16000:
+        opts["gap_open"] = 0
+    maxn = max(5, min(600, 32767 // match))
+    reads = [chimera(rng, targets, rng.randint(5, maxn), both=opts["double_strand"]) for _ in range(4)]
+    run_pair(targets, reads, check_sam=False, **opts)
+
+
 def test_circular_realignment():
     """reads that wrap around the origin of circular contigs (realign_origin, aligners/mod.rs:442-553)"""
     rng = random.Random(3)
