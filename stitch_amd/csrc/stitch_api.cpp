@@ -363,7 +363,25 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     size_t max_job = 0;
     for (size_t k = 0; k < jobs.size(); ++k) { lay[k] = layout_job(c, jobs[k]); max_job = std::max(max_job, lay[k].bytes); }
     // arena: as much of the free memory as useful, at least one job
-    size_t want = 0; for (auto& L : lay) want += L.bytes + sizeof(JobView) + 256;
+    // (a launch never holds more jobs than there are compute units, so more than the largest such window is never used)
+    size_t want = 0;
+    {
+        // (the Local-mode kernel gives a read of T tiles min(4, ceil(T / 250)) workgroups, see the launch loop below)
+        bool all_fast = true; uint32_t gd_min = 4;
+        for (const Job& jb : jobs) {
+            if (!local16_ok(c, jb)) { all_fast = false; break; }
+            uint32_t tiles = 0; for (uint32_t a : jb.act) tiles += (c.al[a].m + 255) / 256;
+            gd_min = std::min(gd_min, std::min(4u, std::max(1u, (tiles + 249u) / 250u)));
+        }
+        const size_t win = all_fast ? std::min<size_t>(jobs.size(), (size_t)std::max(1, c.n_cus) / gd_min) : jobs.size();
+        size_t cur = 0;
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            cur += lay[k].bytes + sizeof(JobView) + sizeof(WalkArgs) + 512;
+            if (k >= win) cur -= lay[k - win].bytes + sizeof(JobView) + sizeof(WalkArgs) + 512;
+            want = std::max(want, cur);
+        }
+        want += (size_t)2 << 20;
+    }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t budget = (size_t)((free_b + c.arena_bytes) * 0.90);
