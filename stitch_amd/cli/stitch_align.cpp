@@ -9,6 +9,7 @@
 // The alignment itself only exists on the GPU: without a device the program stops with the library's error.
 // `--dry-run` parses the inputs and writes the header only (no device needed); `--convert-sam FILE` re-encodes a SAM
 // file as BAM (what `--output-format bam` does to the records it produces) so that the encoder can be tested alone.
+#include <signal.h>
 #include <zlib.h>
 
 #include <cstdint>
@@ -284,6 +285,7 @@ std::string sam_header(const std::vector<std::pair<std::string, uint32_t>>& refs
 }  // namespace
 
 int main(int argc, char** argv) {
+    signal(SIGPIPE, SIG_IGN);            // a closed output pipe is reported by the failing write, not by a silent death
     Args a = parse(argc, argv);
     Out out; out.bam = a.out_format == "bam"; out.level = a.compression;
     BamEncoder enc;
