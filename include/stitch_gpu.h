@@ -100,6 +100,12 @@ typedef struct stitch_timing { double fill_ms, walk_ms, h2d_ms, d2h_ms, host_ms;
                                double prealign_ms /* banded kernel */, prealign_host_ms /* seeds, backbone, band */; } stitch_timing;
 int stitch_last_timing(const stitch_ctx*, stitch_timing* out);
 
+/* Test hook (host only, no device needed): the band of the pre-alignment filter for one (read, target strand) pair as the
+ * library computes it — rows [lo[c], hi[c]) for the columns c = 0..target_len.  Returns 1 when the band is the full matrix
+ * (no seed), 0 otherwise, negative on error.  tests/test_prealign.py compares it with the oracle's restatement. */
+int stitch_prealign_band(const uint8_t* read, uint32_t read_len, const uint8_t* target, uint32_t target_len, uint32_t k, uint32_t w,
+                         int32_t match, int32_t gap_open, int32_t gap_extend, uint16_t* lo, uint16_t* hi);
+
 const char* stitch_last_error(void);
 const char* stitch_version(void);
 

@@ -97,6 +97,15 @@ static Band make_band(const uint8_t* x, size_t m, const uint8_t* y, size_t n, si
     return b;
 }
 
+// the band alone (tests compare it with the product's host code): returns 1 when it is the full matrix
+int banded_band(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match, int32_t go, int32_t ge,
+                uint32_t* lo, uint32_t* hi) {
+    const Band b = make_band(x, m, y, n, k, w, match, go, ge);
+    bool full = true;
+    for (size_t c = 0; c <= n; ++c) { lo[c] = b.lo[c]; hi[c] = b.hi[c]; full = full && b.lo[c] == 0 && b.hi[c] == m + 1; }
+    return full ? 1 : 0;
+}
+
 int32_t banded_local_score(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match,
                            int32_t mismatch, int32_t go, int32_t ge) {
     const Band b = make_band(x, m, y, n, k, w, match, go, ge);

@@ -59,7 +59,7 @@ class _Timing(C.Structure):  # == stitch_timing
 
 EXPORTS = ("stitch_opts_default", "stitch_index_build", "stitch_index_serialize", "stitch_index_deserialize",
            "stitch_index_n_contigs", "stitch_index_destroy", "stitch_ctx_create", "stitch_ctx_destroy", "stitch_align_batch",
-           "stitch_format_sam", "stitch_last_timing", "stitch_last_error", "stitch_version")
+           "stitch_format_sam", "stitch_last_timing", "stitch_prealign_band", "stitch_last_error", "stitch_version")
 
 _lib = None
 

@@ -876,6 +876,19 @@ long stitch_format_sam(stitch_ctx* c, uint32_t read_idx, const char* head, const
     return (long)all.size();
 }
 
+int stitch_prealign_band(const uint8_t* read, uint32_t read_len, const uint8_t* target, uint32_t target_len, uint32_t k, uint32_t w,
+                         int32_t match, int32_t gap_open, int32_t gap_extend, uint16_t* lo, uint16_t* hi) {
+    if (!read || !target || !lo || !hi) return fail(STITCH_EINVAL, "null argument");
+    if (read_len > 65534) return fail(STITCH_EINVAL, "pre_align: reads longer than 65534 bases are not supported");
+    std::vector<Strand> st{Strand{0, target_len}};
+    const KmerIndex ix = build_kmer_index(target, st, k);
+    std::vector<std::vector<Seed>> seeds; std::vector<uint16_t> l, h;
+    find_seeds(ix, target, st, read, read_len, seeds);
+    const bool full = make_band(seeds[0], read_len, target_len, k, w, match, gap_open, gap_extend, l, h);
+    memcpy(lo, l.data(), 2ull * (target_len + 1)); memcpy(hi, h.data(), 2ull * (target_len + 1));
+    return full ? 1 : 0;
+}
+
 int stitch_last_timing(const stitch_ctx* c, stitch_timing* out) {
     if (!c || !out) return fail(STITCH_EINVAL, "null argument");
     *out = c->tm;

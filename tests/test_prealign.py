@@ -97,6 +97,45 @@ def test_oracle_aligners_prealign_logic():
         orc.Aligners(targets, pre_align=True, mode="global").align(read)
 
 
+def _bands(x, y, k, w, match=1, go=-6, ge=-2):
+    import numpy as np
+    from stitch_amd import api
+    xb = (C.c_uint8 * max(1, len(x))).from_buffer_copy((x or "\0").encode()); yb = (C.c_uint8 * max(1, len(y))).from_buffer_copy((y or "\0").encode())
+    lo = np.zeros(len(y) + 1, dtype=np.uint16); hi = np.zeros(len(y) + 1, dtype=np.uint16)
+    L = api.lib()
+    full_p = L.stitch_prealign_band(xb, len(x), yb, len(y), k, w, match, go, ge, lo.ctypes.data_as(C.POINTER(C.c_uint16)), hi.ctypes.data_as(C.POINTER(C.c_uint16)))
+    assert full_p >= 0
+    olo = np.zeros(len(y) + 1, dtype=np.uint32); ohi = np.zeros(len(y) + 1, dtype=np.uint32)
+    full_o = orc.lib().orc_banded_band(xb, C.c_size_t(len(x)), yb, C.c_size_t(len(y)), C.c_size_t(k), C.c_size_t(w), match, go, ge,
+                                      olo.ctypes.data_as(C.POINTER(C.c_uint32)), ohi.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return (full_p, lo.astype(np.uint32), hi.astype(np.uint32)), (full_o, olo, ohi)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_product_band_equals_oracle_band(seed):
+    """the library's host code (sorted k-mer index, analytic diagonal rasterisation) and the oracle's (maps, point by point)
+    must produce the same band, column by column: seeds, backbone chain with its tie-breaks, gaps, extensions"""
+    import numpy as np
+    rng = random.Random(300 + seed)
+    y = rnd(rng, rng.randint(50, 900))
+    kind = seed % 4
+    if kind == 0:
+        x = rnd(rng, rng.randint(20, 600))                                   # unrelated: a few random seeds or none
+    elif kind == 1:
+        a = rng.randint(0, len(y) // 2); x = rnd(rng, rng.randint(0, 80)) + mutate(rng, y[a:a + rng.randint(40, 400)], 0.05, 0.03, 0.03) + rnd(rng, rng.randint(0, 80))
+    elif kind == 2:                                                          # two segments with a big gap, repeats
+        a = rng.randint(0, len(y) // 3); b = rng.randint(len(y) // 2, len(y) - 10)
+        x = y[a:a + 60] + rnd(rng, rng.randint(0, 200)) + y[b:b + 60] + y[a:a + 40]
+    else:
+        unit = rnd(rng, rng.randint(3, 9)); y = (unit * 80)[:len(y)] if rng.random() < 0.5 else y   # low complexity: many seeds, many ties
+        x = (unit * 40)[:rng.randint(30, 250)]
+    k = rng.choice([4, 6, 8, 12]); w = rng.choice([0, 3, 20, 50])
+    go, ge = rng.choice([(-6, -2), (0, -1), (-3, -3)])
+    p, o = _bands(x, y, k, w, match=rng.choice([1, 2]), go=go, ge=ge)
+    assert p[0] == o[0]
+    assert np.array_equal(p[1], o[1]) and np.array_equal(p[2], o[2])
+
+
 # ---- product vs oracle ---------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("opts", [dict(), dict(double_strand=True), dict(pre_align_subset_contigs=False, double_strand=True),
