@@ -1,5 +1,5 @@
 """GPU fuzz of the Local kernel's multi-tile paths (and the pre-alignment filter) against the oracle.  Not collected by pytest:
-run `FUZZ_SECONDS=600 FUZZ_SEED=1000 python tests/gpu_fuzz.py` on a GPU box (round 1: 2051 cases, seeds 1000-3050, all equal)."""
+run `FUZZ_SECONDS=600 FUZZ_SEED=1000 python tests/gpu_fuzz.py` on a GPU box (round 1: 4625 cases, seeds 1000-3050 and 20000-22573, all equal)."""
 import os, random, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import stitch_amd
