@@ -33,6 +33,13 @@ struct FillShared {
 
 namespace {
 
+// Diagnostic build (-DSTITCH_CHECK): every offset the kernel derives is compared with the job's bounds before use; a
+// violation is recorded in the error word (code << 8 | 2) and the access is skipped, so a bad offset shows up as a number
+// instead of a GPU fault.
+#ifdef STITCH_CHECK
+#define CHK_FAIL(errp, code) atomicMax((uint32_t*)(uintptr_t)(errp), ((uint32_t)(code) << 8) | 2u)
+#endif
+
 // In-kernel stamps (diagnostic build only, -DSTITCH_PROFILE): per-wave cycle sums of the column loop's sections, written to
 // the debug area behind V.err.  Never enabled in the product build.
 #ifdef STITCH_PROFILE
@@ -59,6 +66,9 @@ struct GPtrs {                // hot pointers, kept in registers
     gptr<uint32_t> st; gptr<const uint8_t> xseq; gptr<uint8_t> tb;
     gptr<u32x2> yrec;         // y-suffix tracker records {S word, n - j} per row (in the D/Dlen arrays, which this kernel does not use)
     const GPtrsCold* cold;    // in LDS
+#ifdef STITCH_CHECK
+    gptr<uint32_t> chk_err; uint32_t chk_Rtot;
+#endif
 };
 
 // Software pipeline of the tile loop.  hipcc cannot count vmcnt across this loop (conditional memory operations in the body
@@ -67,7 +77,8 @@ struct GPtrs {                // hot pointers, kept in registers
 // after phase A has consumed the registers they land in; when they are needed, at the top of the next slot, the only
 // younger vector-memory operations that may still be in flight are the stores of the tile computed in between (two 16-byte
 // state vectors and the traceback word at 4 rows per lane), hence vmcnt(3).  Extra (conditional) operations only make the
-// wait stricter.
+// wait stricter.  Rule that goes with it: every hand-issued load must be followed by a tile_wait on the same registers on
+// every path, also the one after the last slot — the compiler tracks neither the loads nor the registers they land in.
 #ifndef STITCH_R
 #define STITCH_R 4
 #endif
@@ -193,6 +204,9 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
     const u32x4 cur[4] = {tr.v0, tr.v1, R == 8 ? tr.v2 : tr.v0, R == 8 ? tr.v3 : tr.v1}; const u32x2 curx = tr.x;
     const uint32_t i0 = t * TILE + lane * R + 1;
     const uint32_t r = wc.roff + i0 - 1;
+#ifdef STITCH_CHECK
+    if (r + R > V.chk_Rtot || wc.m > 70000u || t > 300u) { CHK_FAIL(V.chk_err, 0x100000u | (t & 0xFFFu)); return; }
+#endif
     const uint32_t m = wc.m;
     int32_t Sp[R], Dp[R]; uint32_t xb[R];
 #pragma unroll
@@ -386,6 +400,9 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     }
     GPtrs GP;
     GP.st = as_global(V.st16); GP.xseq = as_global(V.xseq); GP.tb = as_global(V.tb); GP.cold = &s_cold;
+#ifdef STITCH_CHECK
+    GP.chk_err = as_global(V.err); GP.chk_Rtot = V.Rtot;
+#endif
     GP.yrec = (gptr<u32x2>)as_global(V.D);           // [Rtot] 8-byte records: D and Dlen are contiguous (layout_job)
     const gptr<uint32_t> st = GP.st;
     const uint32_t C = V.C;
@@ -501,6 +518,9 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     auto slot_rec = [&](uint32_t s) -> u32x4 { return s_slots[s < send ? s : send - 1]; };      // clamped: the pipeline always loads
     auto rec_ptrs = [&](const u32x4& rec, gptr<const u32x4>& ps, gptr<const uint8_t>& px) {
         const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.y), seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.z);
+#ifdef STITCH_CHECK
+        if (row + 64u * R > Rtot || seq > (1u << 26)) { CHK_FAIL(GP.chk_err, 0x200000u | (row >> 12)); ps = (gptr<const u32x4>)st; px = GP.xseq; return; }
+#endif
         ps = (gptr<const u32x4>)(st + 2 * (size_t)(row + lane * R));
         px = GP.xseq + seq + lane * R;
     };
@@ -513,6 +533,10 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
         const JumpBase* base = base2[(j - 1) & 1];
         JumpBase* base_out = base2[j & 1];
         const gptr<uint8_t> tbcol = GP.tb + (size_t)(j - 1) * Rtot;
+#ifdef STITCH_CHECK
+        if (GP.st != as_global(V.st16) || GP.tb != as_global(V.tb) || GP.xseq != as_global(V.xseq) || (gptr<uint32_t>)GP.yrec != as_global((uint32_t*)V.D) || j > n)
+            CHK_FAIL(GP.chk_err, 0x300000u);
+#endif
         // the read's bases, 64 columns per (coalesced) load: lane l holds y[jb + l]
         if (((j - 1) & 63u) == 0) ychunk = (j - 1 + lane < n) ? (uint32_t)V.y[j - 1 + lane] : 0u;
         const uint8_t q = (uint8_t)__builtin_amdgcn_readlane((int)ychunk, (int)((j - 1) & 63u));
@@ -528,6 +552,9 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
             const uint32_t t = (e >> 8) & SLOT_TILE_MASK;
             if (e & SLOT_FIRST) {
                 c = e & 0xFFu;
+#ifdef STITCH_CHECK
+                if (c >= C) { CHK_FAIL(GP.chk_err, 0x400000u | c); c = 0; }
+#endif
                 // best jump out of column j-1 for contig c (multi_contig_aligner.rs:292-331), computed by this wave: lanes hold
                 // the other contigs' column arg-max; inter-contig = max by (score, len), LAST aligner on full ties (max_by_key)
                 const int32_t opp = s_opp[c];
@@ -627,7 +654,10 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
             CmRec cb_; cb_.v = (int32_t)(ck >> 16); cb_.row = 0xFFFFu - (ck & 0xFFFFu); cb_.len = cb_.row != 0 ? cklen : 0u;
             // ---- row m (:350-351 seeded selection, :406-447 for i == m) -----------------------------------------
             {
-                const uint32_t rmi = roff + m - 1;
+                uint32_t rmi = roff + m - 1;
+#ifdef STITCH_CHECK
+                if (rmi >= Rtot || m == 0) { CHK_FAIL(GP.chk_err, 0x500000u); rmi = 0; }
+#endif
                 const int32_t ownS = word_score(rm.F); const uint32_t ownMv = rm.mv, ownSl = word_len(rm.F);
                 int32_t Sm; uint32_t Slm, mvm, lx;
                 lx = xb_.row == 0 ? 0u : m - xb_.row;
@@ -674,6 +704,10 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
             gptr<const u32x4> psn; gptr<const uint8_t> pxn; rec_ptrs(rn, psn, pxn);
             process(e, piece, T, psn, pxn);
         }
+        // The last slot has reloaded itself (slot_rec clamps).  Those loads are hand-issued, so the compiler does not know they
+        // are in flight: without this wait it reuses T's registers after the loop (for the exchange pointers below, or the next
+        // column's slot pointers), the late data lands in them, and the kernel reads through a garbage address.
+        tile_wait(T);
 #ifdef STITCH_PROFILE
         pf_sum[2] += (unsigned long long)wc.n_merge + ((unsigned long long)wc.n_tiles << 32);
 #endif

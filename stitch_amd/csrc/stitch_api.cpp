@@ -389,7 +389,8 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     if (max_job + (1 << 20) > budget) return fail(STITCH_ENOMEM, "one read needs " + std::to_string(max_job >> 20) + " MiB of device memory; only " + std::to_string(budget >> 20) + " MiB usable");
     size_t arena_need = std::min(want + (1 << 20), budget);
     if (arena_need > c.arena_bytes) {
-        if (c.arena) { HIP_TRY(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; }
+        if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] arena %zu -> %zu bytes (%zu jobs)\n", c.arena_bytes, arena_need, jobs.size());
+        if (c.arena) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; }
         HIP_TRY(hipMalloc((void**)&c.arena, arena_need));
         c.arena_bytes = arena_need;
     }
@@ -525,6 +526,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         if (fast) for (uint32_t q = 0; q < nj; ++q) {
             uint32_t e = 0; HIP_TRY(hipMemcpy(&e, views[q].err, 4, hipMemcpyDeviceToHost));
+            if ((e & 0xFFu) == 2u) return fail(STITCH_EINTERNAL, "fill kernel bounds check failed, code " + std::to_string(e >> 8));
             if (e) return fail(STITCH_EINTERNAL, "the fill kernel timed out waiting for a partner (workgroups of one read not co-resident, or a lost hand-off between waves)");
         }
 
