@@ -38,6 +38,7 @@ struct FillShared {
 };
 void launch_fill(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillShared& sh, hipStream_t stream);
 void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, uint32_t max_nact_mode1, hipStream_t stream);
+constexpr size_t PIN_BYTES = (size_t)64 << 20;   // pinned staging buffer for result downloads
 constexpr uint32_t TILE_ROWS = 512;   // 64 lanes x 8 rows (Local-mode kernel; the generic one uses 256): contig row blocks are padded to this
 void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, const FillShared& sh, hipStream_t stream);
 }  // namespace stitch
@@ -82,7 +83,9 @@ struct stitch_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // results of the last batch
     std::vector<stitch_read_result> rr; std::vector<stitch_chain> chains; std::vector<stitch_op> ops;
-    std::vector<std::vector<HAln>> per_read;     // for stitch_format_sam
+    uint8_t* pin = nullptr;                       // pinned staging buffer for result downloads (PIN_BYTES)
+    std::vector<std::vector<HAln>> job_chains;   // final chains per job (a run of identical reads shares one job)
+    std::vector<long> per_read;                  // read -> index into job_chains, -1 = none; for stitch_format_sam
     stitch_timing tm{};
     int n_cus = 256; uint32_t tm_wg_per_read = 1;
     bool tm_fast = false;                        // last run_jobs used the Local-mode 16-bit kernel
@@ -181,6 +184,7 @@ void stitch_ctx_destroy(stitch_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_xseq, c->d_S0, c->d_Slen0, c->d_Sn0, c->d_SnSet0, c->d_Smove0, c->d_Imove0, c->d_lx0, c->d_base0, c->arena, c->pre_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->pin) (void)hipHostFree(c->pin);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -197,7 +201,7 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     if (o->pre_align && (o->kmer_size < 1 || o->band_width < 0)) return fail(STITCH_EINVAL, "bad k-mer size or band width");
     const uint32_t T = (uint32_t)idx->names.size();
     const uint32_t C = T * (o->double_strand ? 2u : 1u);
-    if (C > 255) return fail(STITCH_EINVAL, "more than 255 contig-strands (packed_length_cell.rs:112-114)");
+    if (C > 256) return fail(STITCH_EINVAL, "more than 256 contig-strands: the reference's traceback cell holds contig indexes 0..255 (packed_length_cell.rs:112-114, 139)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(STITCH_EDEVICE, "no HIP device: this library has no CPU path");
     if (device_ordinal < 0 || device_ordinal >= ndev) return fail(STITCH_EDEVICE, "bad device ordinal");
@@ -384,14 +388,28 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    size_t budget = (size_t)((free_b + c.arena_bytes) * 0.90);
+    size_t budget = (size_t)(std::min(free_b + c.arena_bytes, total_b) * 0.90);
     if (c.mem_limit) budget = std::min(budget, c.mem_limit);
     if (max_job + (1 << 20) > budget) return fail(STITCH_ENOMEM, "one read needs " + std::to_string(max_job >> 20) + " MiB of device memory; only " + std::to_string(budget >> 20) + " MiB usable");
     size_t arena_need = std::min(want + (1 << 20), budget);
     if (arena_need > c.arena_bytes) {
-        if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] arena %zu -> %zu bytes (%zu jobs)\n", c.arena_bytes, arena_need, jobs.size());
-        if (c.arena) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; }
-        HIP_TRY(hipMalloc((void**)&c.arena, arena_need));
+        if (c.arena) {
+            HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0;
+            // ask again now that the old arena is gone: what the runtime reported as free while it was held need not add up
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            size_t b2 = (size_t)(free_b * 0.90);
+            if (c.mem_limit) b2 = std::min(b2, c.mem_limit);
+            arena_need = std::min(arena_need, std::max(b2, max_job + ((size_t)1 << 20)));
+        }
+        // a smaller arena only means more launches: shrink until the allocation succeeds or one read no longer fits
+        for (;;) {
+            if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] arena -> %zu bytes (%zu jobs, %zu free)\n", arena_need, jobs.size(), free_b);
+            if (hipMalloc((void**)&c.arena, arena_need) == hipSuccess) break;
+            (void)hipGetLastError(); c.arena = nullptr;
+            const size_t smaller = std::max(max_job + ((size_t)1 << 20), (size_t)(arena_need * 0.85));
+            if (smaller >= arena_need) return fail(STITCH_ENOMEM, "cannot allocate " + std::to_string(arena_need >> 20) + " MiB of device memory for one read");
+            arena_need = smaller;
+        }
         c.arena_bytes = arena_need;
     }
     FillShared sh{c.d_S0, c.d_Slen0, c.d_Sn0, c.d_SnSet0, c.d_Smove0, c.d_lx0, c.d_base0};
@@ -499,7 +517,10 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             // the waves of a workgroup share its tiles evenly (fill_local16.hip), so use all 12 unless there are fewer tiles
             uint32_t min_tiles = 0xFFFFFFFFu;
             for (uint32_t q = 0; q < nj; ++q) { uint32_t t = 0; for (uint32_t a : jobs[k0 + q].act) t += (c.al[a].m + 255) / 256; min_tiles = std::min(min_tiles, t / G); }
-            waves = (int)std::max(1u, std::min<uint32_t>(MAX_WAVES_LOCAL, min_tiles));
+            // ... of a few tiles each: a contig cut across waves is a serial chain of hand-offs within a column (about 1 us
+            // each), which dominates when a workgroup holds only a contig or two (re-alignment jobs on a chain's contigs)
+            uint32_t tpw = 5; if (const char* e = getenv("STITCH_TILES_PER_WAVE")) tpw = (uint32_t)std::max(1, atoi(e));
+            waves = (int)std::max(1u, std::min<uint32_t>(MAX_WAVES_LOCAL, min_tiles / tpw));
             if (const char* e = getenv("STITCH_MAX_WAVES")) waves = std::max(1, std::min(waves, atoi(e)));
         }
         c.tm_wg_per_read = G;
@@ -515,8 +536,10 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         HIP_TRY(hipEventRecord(c.ev[2], c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, c.ev[0], c.ev[1])); c.tm.fill_ms += ms;
+        float ms_fill = 0;
+        HIP_TRY(hipEventElapsedTime(&ms_fill, c.ev[0], c.ev[1])); c.tm.fill_ms += ms_fill;
         HIP_TRY(hipEventElapsedTime(&ms, c.ev[1], c.ev[2])); c.tm.walk_ms += ms;
+        if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms, fix-up + walk %.1f ms\n", nj, G, waves, ms_fill, ms);
         c.tm.launches += 1; c.tm.jobs += nj;
         if (getenv("STITCH_PROFILE_DUMP") && fast) {
             unsigned long long pf[128]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[0].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
@@ -530,15 +553,41 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             if (e) return fail(STITCH_EINTERNAL, "the fill kernel timed out waiting for a partner (workgroups of one read not co-resident, or a lost hand-off between waves)");
         }
 
-        // download chains
+        // download chains: headers first, then the operation lists, both batched through a pinned staging buffer (one
+        // synchronous pageable copy per chain costs ~0.15 ms each; --suboptimal yields hundreds of chains per read)
         auto t_d2h0 = std::chrono::steady_clock::now();
+        if (!c.pin) { HIP_TRY(hipHostMalloc((void**)&c.pin, PIN_BYTES, hipHostMallocDefault)); }
+        struct Pending { void* dst; const uint8_t* src; size_t bytes; };
+        std::vector<Pending> pend;
+        auto flush = [&]() -> int {
+            size_t i = 0;
+            while (i < pend.size()) {
+                if (pend[i].bytes > PIN_BYTES) { HIP_TRY(hipMemcpy(pend[i].dst, pend[i].src, pend[i].bytes, hipMemcpyDeviceToHost)); ++i; continue; }
+                size_t used = 0, j = i;
+                while (j < pend.size() && used + pend[j].bytes <= PIN_BYTES) {
+                    HIP_TRY(hipMemcpyAsync(c.pin + used, pend[j].src, pend[j].bytes, hipMemcpyDeviceToHost, c.stream));
+                    used += align_up(pend[j].bytes, 64); ++j;
+                }
+                HIP_TRY(hipStreamSynchronize(c.stream));
+                used = 0;
+                for (size_t k = i; k < j; ++k) { memcpy(pend[k].dst, c.pin + used, pend[k].bytes); used += align_up(pend[k].bytes, 64); }
+                i = j;
+            }
+            pend.clear();
+            return STITCH_OK;
+        };
+        std::vector<std::vector<ChainHdr>> hdrs(nj);
+        for (uint32_t q = 0; q < nj; ++q) {
+            const JobLayout& L = lay[k0 + q];
+            hdrs[q].resize(L.slots);
+            pend.push_back({hdrs[q].data(), c.arena + base[q] + L.off_hdr, sizeof(ChainHdr) * (size_t)L.slots});
+        }
+        if (int e = flush()) return e;
         for (uint32_t q = 0; q < nj; ++q) {
             Job& jb = jobs[k0 + q]; const JobLayout& L = lay[k0 + q]; uint8_t* B = c.arena + base[q];
-            std::vector<ChainHdr> hdrs(L.slots);
-            HIP_TRY(hipMemcpy(hdrs.data(), B + L.off_hdr, sizeof(ChainHdr) * (size_t)L.slots, hipMemcpyDeviceToHost));
             jb.chains.assign(L.slots, HAln()); jb.status.assign(L.slots, 0);
             for (uint32_t s = 0; s < L.slots; ++s) {
-                ChainHdr H = hdrs[s];
+                ChainHdr H = hdrs[q][s];
                 const uint8_t* ops_src = B + L.off_ops + sizeof(OpRec) * (size_t)s * L.ops_cap;
                 uint8_t* big = nullptr;
                 if (H.status == 2) {
@@ -559,15 +608,20 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
                 if (H.status == 4) { if (big) (void)hipFree(big); return fail(STITCH_EINVAL, "end-of-read jump into a shorter contig: the reference indexes its traceback matrix out of range here (traceback/mod.rs:329-338); result undefined"); }
                 if (H.status >= 2) { if (big) (void)hipFree(big); return fail(STITCH_EINTERNAL, "traceback failed on the device (status " + std::to_string(H.status) + ")"); }
                 if (H.status == 1) { if (big) (void)hipFree(big); continue; }
+                if ((size_t)H.n_ops > (big ? (size_t)H.n_ops : (size_t)L.ops_cap)) return fail(STITCH_EINTERNAL, "chain header reports more operations than its buffer holds");
                 HAln& a = jb.chains[s];
                 a.score = H.score; a.xstart = H.xstart; a.xend = H.xend; a.ystart = H.ystart; a.yend = H.yend; a.xlen = H.xlen; a.ylen = H.ylen;
                 a.start_contig_idx = H.start_contig_idx; a.end_contig_idx = H.end_contig_idx; a.length = H.length;
                 a.ops.resize(H.n_ops);
                 static_assert(sizeof(OpRec) == sizeof(stitch_op), "op layout");
-                if (H.n_ops) HIP_TRY(hipMemcpy(a.ops.data(), ops_src, sizeof(OpRec) * (size_t)H.n_ops, hipMemcpyDeviceToHost));
+                if (H.n_ops) {
+                    if (big) { HIP_TRY(hipMemcpy(a.ops.data(), ops_src, sizeof(OpRec) * (size_t)H.n_ops, hipMemcpyDeviceToHost)); }
+                    else pend.push_back({a.ops.data(), ops_src, sizeof(OpRec) * (size_t)H.n_ops});
+                }
                 if (big) (void)hipFree(big);
             }
         }
+        if (int e = flush()) return e;
         c.tm.d2h_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d2h0).count();
         k0 = k1;
     }
@@ -685,7 +739,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
 }
 
 // traceback_all's selection loop over per-end-contig candidate chains (traceback/mod.rs:152-217)
-std::vector<HAln> select_all(const stitch_ctx& c, const Job& jb) {
+std::vector<HAln> select_all(const stitch_ctx& c, Job& jb) {           // (moves the selected chains out of the job)
     std::vector<HAln> out;
     std::vector<uint8_t> consider(c.C, 0), seen(c.C, 0);
     for (uint32_t a : jb.act) consider[a] = 1;
@@ -701,10 +755,10 @@ std::vector<HAln> select_all(const stitch_ctx& c, const Job& jb) {
             if (s > score || (s == score && l > alen)) { pick = k; score = s; alen = l; }
         }
         if (jb.status[pick] == 1) { mark(jb.act[pick]); continue; }
-        const HAln& a = jb.chains[pick];
+        HAln& a = jb.chains[pick];
         mark(a.start_contig_idx); mark(a.end_contig_idx);
         for (const stitch_op& op : a.ops) if (op.kind == OP_XJUMP) mark(op.contig);
-        out.push_back(a);
+        out.push_back(std::move(a));
     }
     return out;
 }
@@ -718,7 +772,6 @@ struct RealignPlan {                                // realign_origin (mod.rs:44
 };
 
 void plan_realign(const stitch_ctx& c, const std::vector<uint8_t>& query, const HAln& aln, std::vector<Job>& jobs, RealignPlan& plan) {
-    plan.original = aln;
     const uint32_t slop = (uint32_t)c.opts.circular_slop;
     const bool circ = c.opts.circular != 0;          // is_circular(): every aligner carries opts.circular (mod.rs:191,201)
     bool at_start = aln.xstart <= slop && circ, at_end = aln.xlen <= aln.xend + slop && circ;      // :365-385
@@ -729,6 +782,7 @@ void plan_realign(const stitch_ctx& c, const std::vector<uint8_t>& query, const 
     if (at_end && aln.ystart == 0) at_end = false;
     if (!at_start && !at_end) return;
     plan.needed = true;
+    plan.original = aln;
     std::vector<uint8_t> in(c.C, 0);
     in[aln.start_contig_idx] = 1; in[aln.end_contig_idx] = 1;
     for (const stitch_op& op : aln.ops) if (op.kind == OP_XJUMP) in[op.contig] = 1;
@@ -780,7 +834,7 @@ int stitch_align_batch(stitch_ctx* c, const uint8_t* bases, const uint64_t* offs
     if (!c || (!bases && n_reads) || !offsets) return fail(STITCH_EINVAL, "null argument");
     auto t_host0 = std::chrono::steady_clock::now();
     c->tm = stitch_timing{};
-    c->rr.clear(); c->chains.clear(); c->ops.clear(); c->per_read.assign(n_reads, {});
+    c->rr.clear(); c->chains.clear(); c->ops.clear(); c->per_read.assign(n_reads, -1); c->job_chains.clear();
     std::vector<uint32_t> all(c->C); for (uint32_t a = 0; a < c->C; ++a) all[a] = a;
 
     // pass 1: one job per run of identical consecutive reads (FastxGroupingIterator, align/io.rs:118-146)
@@ -809,8 +863,12 @@ int stitch_align_batch(stitch_ctx* c, const uint8_t* bases, const uint64_t* offs
         for (size_t k = 0; k < jobs.size(); ++k) if (pre_has[k]) { live_of.push_back(k); live.push_back(std::move(jobs[k])); }
         jobs.swap(live);
     } else { live_of.resize(jobs.size()); for (size_t k = 0; k < jobs.size(); ++k) live_of[k] = k; }
+    const bool dbg = getenv("STITCH_DEBUG") != nullptr;
+    auto stamp = [&](const char* what) { if (dbg) fprintf(stderr, "[stitch] %-28s at %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count()); };
+    stamp("jobs built / pre-aligned");
     rc = run_jobs(*c, jobs);
     if (rc) return rc;
+    stamp("pass 1 done");
 
     // host: chains of pass 1, realign planning
     struct PerJob { std::vector<HAln> chains; std::vector<RealignPlan> plans; };
@@ -819,13 +877,15 @@ int stitch_align_batch(stitch_ctx* c, const uint8_t* bases, const uint64_t* offs
     for (size_t k = 0; k < jobs.size(); ++k) {
         std::vector<HAln> cand;
         if (c->opts.suboptimal) cand = select_all(*c, jobs[k]);
-        else { if (jobs[k].status[0] != 0) return fail(STITCH_EINTERNAL, "primary traceback returned None"); cand.push_back(jobs[k].chains[0]); }
+        else { if (jobs[k].status[0] != 0) return fail(STITCH_EINTERNAL, "primary traceback returned None"); cand.push_back(std::move(jobs[k].chains[0])); }
         for (HAln& a : cand) { if (!c->opts.keep_clipping) remove_clipping(c->opts, a); }
-        pj[k].chains = cand;
-        pj[k].plans.resize(cand.size());
-        if (c->opts.circular) for (size_t q = 0; q < cand.size(); ++q) plan_realign(*c, jobs[k].y, cand[q], jobs2, pj[k].plans[q]);
+        pj[k].chains = std::move(cand);
+        pj[k].plans.resize(pj[k].chains.size());
+        if (c->opts.circular) for (size_t q = 0; q < pj[k].chains.size(); ++q) plan_realign(*c, jobs[k].y, pj[k].chains[q], jobs2, pj[k].plans[q]);
     }
+    stamp("chains selected, realign planned");
     if (!jobs2.empty()) { rc = run_jobs(*c, jobs2); if (rc) return rc; }
+    stamp("pass 2 done");
     for (size_t k = 0; k < jobs.size(); ++k) {
         for (size_t q = 0; q < pj[k].chains.size(); ++q)
             if (pj[k].plans[q].needed) pj[k].chains[q] = finish_realign(*c, pj[k].plans[q], jobs2);
@@ -833,18 +893,23 @@ int stitch_align_batch(stitch_ctx* c, const uint8_t* bases, const uint64_t* offs
         if (c->opts.suboptimal && al.size() > 1) {                                        // mod.rs:318-329
             std::stable_sort(al.begin(), al.end(), [](const HAln& a, const HAln& b) { return -a.score < -b.score; });
             const float min_score = (float)al[0].score * c->opts.suboptimal_pct / 100.0f;
-            std::vector<HAln> kept; for (HAln& a : al) if ((float)a.score >= min_score) kept.push_back(a);
+            std::vector<HAln> kept; for (HAln& a : al) if ((float)a.score >= min_score) kept.push_back(std::move(a));
             al.swap(kept);
         }
     }
+    stamp("realign finished, sorted");
     // result arena, input order
     c->rr.resize(n_reads);
     std::vector<long> live_idx(n_jobs_all, -1);
     for (size_t l = 0; l < live_of.size(); ++l) live_idx[live_of[l]] = (long)l;
     static const std::vector<HAln> none;
+    c->job_chains.resize(pj.size());
+    for (size_t k = 0; k < pj.size(); ++k) c->job_chains[k] = std::move(pj[k].chains);
+    { size_t n_ops = 0; for (uint32_t r = 0; r < n_reads; ++r) { const long l = live_idx[job_of[r]]; if (l >= 0) for (const HAln& a : c->job_chains[(size_t)l]) n_ops += a.ops.size(); }
+      c->ops.reserve(n_ops); }
     for (uint32_t r = 0; r < n_reads; ++r) {
         const long l = live_idx[job_of[r]];
-        const std::vector<HAln>& al = l >= 0 ? pj[(size_t)l].chains : none;
+        const std::vector<HAln>& al = l >= 0 ? c->job_chains[(size_t)l] : none;
         stitch_read_result& R = c->rr[r]; memset(&R, 0, sizeof(R));
         if (c->opts.pre_align && pre_has[job_of[r]]) { R.has_prealign = 1; R.prealign_score = pre_score[job_of[r]]; }
         R.chains_begin = c->chains.size(); R.n_chains = (uint32_t)al.size();
@@ -855,13 +920,14 @@ int stitch_align_batch(stitch_ctx* c, const uint8_t* bases, const uint64_t* offs
             c->ops.insert(c->ops.end(), a.ops.begin(), a.ops.end());
             c->chains.push_back(ch);
         }
-        c->per_read[r] = al;
+        c->per_read[r] = l;
     }
     if (per_read) *per_read = c->rr.data();
     if (chains) *chains = c->chains.data();
     if (ops) *ops = c->ops.data();
     if (cells_filled) *cells_filled = c->tm.cells;
     c->tm.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    stamp("result arena built");
     return STITCH_OK;
 }
 
@@ -869,8 +935,9 @@ long stitch_format_sam(stitch_ctx* c, uint32_t read_idx, const char* head, const
                        size_t n, char* buf, size_t cap) {
     if (!c || !head || !bases) return fail(STITCH_EINVAL, "null argument");
     if (read_idx >= c->per_read.size()) return fail(STITCH_EINVAL, "read_idx outside the last batch");
+    static const std::vector<HAln> none_chains;
     std::vector<std::string> recs; std::string err;
-    if (!format_sam_records(c->opts, c->targets, head, bases, quals, n, c->per_read[read_idx], c->rr[read_idx].has_prealign != 0,
+    if (!format_sam_records(c->opts, c->targets, head, bases, quals, n, c->per_read[read_idx] >= 0 ? c->job_chains[(size_t)c->per_read[read_idx]] : none_chains, c->rr[read_idx].has_prealign != 0,
                             c->rr[read_idx].prealign_score, recs, err)) return fail(STITCH_EINVAL, err);
     std::string all;
     for (size_t k = 0; k < recs.size(); ++k) { if (k) all += "\n"; all += recs[k]; }

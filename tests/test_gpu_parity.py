@@ -228,6 +228,28 @@ def test_circular_realignment():
     run_pair(targets, reads, circular=True, suboptimal=True, double_strand=True)
 
 
+def test_cfg5_shape_many_circular_contigs_suboptimal():
+    """BASELINE config 5 in miniature: 200 circular contigs (more contigs than lanes in a wavefront, many workgroups per
+    read), PacBio-like reads that wrap around origins, --circular --suboptimal; chains and SAM text against the oracle"""
+    db = synth.make_db(200, 150, 1002)
+    targets = [(n, s.decode()) for n, s in db]
+    reads = [r.decode() for r in synth.make_reads(db, 5, 600, 47, sub=0.01, ins=0.005, dele=0.005, circular=True)]
+    run_pair(targets, reads, circular=True, suboptimal=True)
+    run_pair(targets[:120], reads[:2], circular=True, suboptimal=True, double_strand=True, check_sam=False)   # 240 contig-strands (255 is the reference's limit)
+
+
+def test_error_behaviour_matches_the_reference():
+    """what the reference refuses, the product refuses (an error code and a message, never a silent fallback): contig
+    indexes above 255 (packed_length_cell.rs:112-114, 139), and the oracle agrees; 256 contig-strands still work"""
+    rng = random.Random(9)
+    many = [(f"c{k}", rand_seq(rng, 20)) for k in range(129)]
+    with pytest.raises(stitch_amd.StitchError, match="256 contig-strands"):
+        stitch_amd.Builder(double_strand=True).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in many]).align(["ACGTACGTAC"])
+    with pytest.raises(RuntimeError):
+        orc.Aligners(many, double_strand=True).align("ACGTACGTAC")
+    run_pair(many[:128], ["ACGTACGTAC" * 3, many[127][1] + rc(many[3][1])], double_strand=True)      # indexes 0..255
+
+
 def test_batch_split_invariance_and_determinism(monkeypatch):
     """results do not depend on how reads are packed into launches; two runs are identical"""
     db = synth.make_db(4, 600, 9)
