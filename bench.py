@@ -138,7 +138,9 @@ def main():
         # the committed rocprofv3 --pmc measurement (profiles/, separate FETCH_SIZE and WRITE_SIZE passes of this same
         # command, KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) scaled per cell.
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_local16.json")))
+            import glob
+            pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_local16.json")))[-1]        # the latest committed pass
+            pmc = json.load(open(pmc_path))
             k = pmc["stitch::fill_local16_kernel"]
             bpc = (2.0 * k["FETCH_SIZE"]["avg_per_launch_raw"] + k["WRITE_SIZE"]["avg_per_launch_raw"]) * 1024.0 / pmc["cells_per_launch"]
             out["roofline"]["traffic"] = bpc * cells / max(1, launches)
@@ -147,9 +149,9 @@ def main():
             vpc = k["SQ_INSTS_VALU"]["avg_per_launch_raw"] * 64.0 / pmc["cells_per_launch"]
             out["roofline"]["valu"] = {"wave_insts_per_64_cells": vpc, "achieved_wave_insts_per_s": vpc * (cells / 64.0) / fill_s,
                                        "peak_wave_insts_per_s": 256 * 4 * 2.4e9 / 4, "frac": vpc * (cells / 64.0) / fill_s / (256 * 4 * 2.4e9 / 4)}
-            out["roofline"]["traffic_source"] = ("profiles/r01_e_pmc_local16.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch of "
+            out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(pmc_path)}: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch of "
                                                  f"{pmc['cells_per_launch']:.3g} cells = {bpc:.2f} B/cell, scaled to this run's cells per launch")
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, IndexError, TypeError):
             pass
         if world == 1 and args.cpu_reads > 0:
             from oracle import oracle as orc

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects the numbers profiles/ holds, on a GPU box (run from the repository root):
+#   bash profiles/collect.sh r01_g
+# 1. bench.py as the driver runs it            -> profiles/<tag>_bench_local16.json
+# 2. rocprofv3 --kernel-trace --stats of that   -> profiles/<tag>_kernel_stats_local16.csv
+# 3. PMC counters, one pass per group (TCC FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md), never
+#    combined with a trace domain                                                        -> profiles/<tag>_pmc_local16.json
+# The program follows `--` directly (no env/bash wrapper: the profiler has initialised the GPU by then).
+set -o pipefail
+tag=${1:-r01_x}
+out=gpurun_out/collect_$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; exit 1; }
+cp "$out/bench.json" "profiles/${tag}_bench_local16.json"
+rocprofv3 --kernel-trace --stats -d "$out/trace" -o run --output-format csv -- python3 bench.py --cpu-reads 0 > "$out/trace.log" 2>&1 || { echo "trace failed"; exit 1; }
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
+  d="$out/pmc_$(echo $grp | tr ' ' '_' | cut -c1-40)"
+  rocprofv3 --pmc $grp -d "$d" -o run --output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-reads 0 > "$d.log" 2>&1 || { echo "pmc $grp failed"; exit 1; }
+  echo "pmc $grp done" >> "$out/progress.txt"
+done
+python3 profiles/summarize.py "$out" "$tag"
+cp profiles/${tag}_* "$out/"        # gpurun merges only gpurun_out/ back: copy from there into profiles/ and commit
