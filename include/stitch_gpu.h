@@ -97,7 +97,8 @@ long stitch_format_sam(stitch_ctx*, uint32_t read_idx, const char* head, const u
  * fill_ms = sum over launches of the DP fill kernel, walk_ms = fix-up + traceback kernel, launches = number of
  * fill launches, cells = DP cells filled by them.  Used by bench.py for the roofline line. */
 typedef struct stitch_timing { double fill_ms, walk_ms, h2d_ms, d2h_ms, host_ms; uint64_t cells; uint32_t launches; uint32_t jobs;
-                               double prealign_ms /* banded kernel */, prealign_host_ms /* seeds, backbone, band */; } stitch_timing;
+                               double prealign_ms /* banded kernels incl. their transfers */, prealign_host_ms /* seeds, backbone, band: runs on host
+                                  threads concurrently with prealign_ms of the chunk before, so the two overlap */; } stitch_timing;
 int stitch_last_timing(const stitch_ctx*, stitch_timing* out);
 
 /* Test hook (host only, no device needed): the band of the pre-alignment filter for one (read, target strand) pair as the

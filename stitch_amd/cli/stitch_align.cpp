@@ -177,7 +177,7 @@ struct BamEncoder {
 struct Args {
     std::string reads_fastq, reads_fasta, ref_fasta, out_format = "sam", convert_sam;
     stitch_opts o; int jump_score = -10; bool js_same = false, js_opp = false, js_inter = false;
-    int threads = 2, compression = 0, device = 0; uint32_t batch = 256; bool decompress = false, dry_run = false;
+    int threads = 2, compression = 0, device = 0; uint32_t batch = 1024; bool decompress = false, dry_run = false;
 };
 
 const char* USAGE =
@@ -200,7 +200,7 @@ const char* USAGE =
     "      --suboptimal            --suboptimal-pct X (20)\n"
     "  -c, --compression N         BGZF level of the BAM output (0)\n"
     "      --output-format FMT     sam (default) | bam\n"
-    "      --device N  --batch N   GPU ordinal (0), reads per library call (256)\n"
+    "      --device N  --batch N   GPU ordinal (0), reads per library call (1024)\n"
     "      --dry-run               parse the inputs, write the header, align nothing (no GPU needed)\n";
 
 bool parse_bool(const std::string& v, bool& out) {

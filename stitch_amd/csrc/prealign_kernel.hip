@@ -84,6 +84,88 @@ __global__ __launch_bounds__(64) void banded_score_kernel(const BandPair* __rest
     if (lane == 0) scores[pid] = best;
 }
 
+// The same recurrence with the column state on chip: H (two columns) and D live in LDS rings of BAND_RING rows indexed by
+// row mod BAND_RING, which holds any band whose columns are at most BAND_RING rows tall (the host sends taller ones to
+// the kernel above); the read's bases are staged in LDS once; the band ranges and target bases of 64 columns are
+// fetched together and broadcast from registers.  Rows are tied to lanes by row mod 64, so a column is processed in
+// 64-aligned blocks of rows and the insertion chain is a DPP prefix maximum in 32 bits (keys T - ge*i >= 0, "none" = -1;
+// the host checks that they fit).  One wavefront per pair, no barriers: a wavefront's LDS operations execute in order.
+constexpr uint32_t BAND_RING = 1024;
+constexpr size_t BAND_LDS_MAX = 64 << 10;
+__device__ __forceinline__ int32_t dpp_max_shr(int32_t v, int32_t none) {            // inclusive prefix maximum over the 64 lanes
+#define STITCH_DPP_STEP(CTRL, ROWMASK) { const int32_t o = __builtin_amdgcn_update_dpp(none, v, CTRL, ROWMASK, 0xF, false); v = o > v ? o : v; }
+    STITCH_DPP_STEP(0x111, 0xF) STITCH_DPP_STEP(0x112, 0xF) STITCH_DPP_STEP(0x114, 0xF) STITCH_DPP_STEP(0x118, 0xF)      // row_shr 1, 2, 4, 8
+    STITCH_DPP_STEP(0x142, 0xA) STITCH_DPP_STEP(0x143, 0xC)                                                          // row_bcast 15, 31
+#undef STITCH_DPP_STEP
+    return v;
+}
+__global__ __launch_bounds__(64) void banded_score_lds_kernel(const BandPair* __restrict__ pairs, const uint32_t* __restrict__ which, BandScoring sc,
+                                                              const uint8_t* __restrict__ reads, const uint8_t* __restrict__ contigs,
+                                                              const uint16_t* __restrict__ bands, int32_t* __restrict__ scores) {
+    extern __shared__ int32_t band_lds[];
+    const uint32_t pid = which[blockIdx.x];
+    const BandPair P = pairs[pid];
+    const int lane = threadIdx.x;
+    const uint32_t m = P.m, n = P.n;
+    const uint8_t* q = reads + P.q_off; const uint8_t* t = contigs + P.t_off;
+    const uint16_t* lo = bands + P.band_off; const uint16_t* hi = lo + (n + 1);
+    int32_t* H0 = band_lds; int32_t* H1 = H0 + BAND_RING; int32_t* D = H1 + BAND_RING;
+    uint8_t* qs = (uint8_t*)(D + BAND_RING);
+    for (uint32_t i = lane; i < m; i += 64) qs[i] = q[i];
+    const int32_t go = sc.gap_open, ge = sc.gap_extend, NONE = -1;
+    constexpr uint32_t RM = BAND_RING - 1;
+    int32_t best = 0;
+    uint32_t plo = lo[0], phi = hi[0];                               // raw range of column j - 1
+    uint32_t vlo = 0, vhi = 0, vt = 0;
+    for (uint32_t j = 1; j <= n; ++j) {
+        const uint32_t jl = (j - 1) & 63u;
+        if (jl == 0) {                                                // ranges and target bases of columns j .. j + 63
+            const uint32_t c = j + (uint32_t)lane;
+            vlo = c <= n ? lo[c] : 0u; vhi = c <= n ? hi[c] : 0u; vt = c <= n ? t[c - 1] : 0u;
+        }
+        const uint32_t clo = (uint32_t)__builtin_amdgcn_readlane((int)vlo, (int)jl), chi = (uint32_t)__builtin_amdgcn_readlane((int)vhi, (int)jl);
+        const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)vt, (int)jl);
+        const uint32_t r0 = max(clo, 1u), r1 = min(chi, m + 1);
+        if (r0 < r1) {
+            const int32_t* Hp = (j & 1) ? H0 : H1; int32_t* Hc = (j & 1) ? H1 : H0;
+            int32_t carry = r0 == 1 ? 0 : NONE;                       // row 0 holds H = 0: T(0) - ge*0
+            for (uint32_t b = r0 >> 6; b <= (r1 - 1) >> 6; ++b) {
+                const uint32_t i = (b << 6) + (uint32_t)lane;
+                const bool valid = i >= r0 && i < r1;
+                int32_t T = 0, d = MIN_SCORE, key = NONE;
+                if (valid) {
+                    int32_t hd, hl, dl;
+                    if (j == 1) { hd = 0; hl = 0; dl = MIN_SCORE; }
+                    else {
+                        hd = i == 1 ? 0 : ((i - 1 >= plo && i - 1 < phi) ? Hp[(i - 1) & RM] : MIN_SCORE);
+                        const bool in = i >= plo && i < phi;
+                        hl = in ? Hp[i & RM] : MIN_SCORE; dl = in ? D[i & RM] : MIN_SCORE;
+                    }
+                    d = max(max(dl + ge, hl + go + ge), MIN_SCORE);
+                    const int32_t s = (uint32_t)qs[i - 1] == tj ? sc.match : sc.mismatch;
+                    T = max(max(max(hd + s, MIN_SCORE), d), 0);
+                    key = T - ge * (int32_t)i;
+                }
+                const int32_t incl = dpp_max_shr(key, NONE);
+                int32_t pre = __builtin_amdgcn_update_dpp(NONE, incl, 0x138, 0xF, 0xF, false);     // wave_shr 1: the lanes before this one
+                pre = carry > pre ? carry : pre;
+                if (valid) {
+                    const int32_t I = pre < 0 ? MIN_SCORE : max(pre + go + ge * (int32_t)i, MIN_SCORE);
+                    const int32_t h = max(T, I);
+                    Hc[i & RM] = h; D[i & RM] = d;
+                    best = max(best, h);
+                }
+                const int32_t tail = __builtin_amdgcn_readlane(incl, 63);
+                carry = tail > carry ? tail : carry;
+            }
+        }
+        plo = clo; phi = chi;
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) best = max(best, __shfl_xor(best, dd, 64));
+    if (lane == 0) scores[pid] = best;
+}
+
 // Pairs without a single k-mer match are scored over the FULL matrix (the band is everything): ~5 % of the pairs of a random
 // 10 kb read against 5 kb targets, 50 M cells each.  One workgroup per pair, H and D of all rows in LDS, the rows dealt in
 // contiguous slices to the threads: per column a thread (1) computes D and T = max(0, diagonal, D) of its rows and the
@@ -242,6 +324,19 @@ uint32_t full_score_max_rows() { return FULL_MAX_ROWS; }
 void launch_banded_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
                           const uint16_t* d_bands, int32_t* d_state, int32_t* d_scores, hipStream_t stream) {
     if (n_pairs) hipLaunchKernelGGL(banded_score_kernel, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_bands, d_state, d_scores);
+}
+// pairs whose band columns are at most banded_ring_rows() tall and whose reads are at most max_m long; false = not applicable
+// (scores or keys do not fit 32 bits, or the read does not fit in LDS): the caller uses launch_banded_scores for them too
+uint32_t banded_ring_rows() { return BAND_RING; }
+bool launch_banded_scores_lds(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, uint32_t max_m, const BandScoring& sc, const uint8_t* d_reads,
+                              const uint8_t* d_contigs, const uint16_t* d_bands, int32_t* d_scores, hipStream_t stream) {
+    const long long big = (long long)1 << 29;
+    const bool small = (long long)std::abs(sc.match) * (max_m + 1) < big && (long long)std::abs(sc.gap_extend) * (max_m + 2) + std::abs(sc.gap_open) < big &&
+                       std::abs((long long)sc.mismatch) < big && sc.gap_extend <= 0 && sc.gap_open <= 0;
+    const size_t lds = (size_t)BAND_RING * 12 + ((size_t)max_m + 3) / 4 * 4;
+    if (!small || lds > BAND_LDS_MAX) return false;
+    if (n_pairs) hipLaunchKernelGGL(banded_score_lds_kernel, dim3(n_pairs), dim3(64), lds, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_bands, d_scores);
+    return true;
 }
 
 }  // namespace stitch

@@ -29,6 +29,9 @@
 namespace stitch {
 void launch_banded_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
                           const uint16_t* d_bands, int32_t* d_state, int32_t* d_scores, hipStream_t stream);
+uint32_t banded_ring_rows();
+bool launch_banded_scores_lds(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, uint32_t max_m, const BandScoring& sc, const uint8_t* d_reads,
+                              const uint8_t* d_contigs, const uint16_t* d_bands, int32_t* d_scores, hipStream_t stream);
 void launch_full_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_full, uint32_t max_m, const BandScoring& sc, const uint8_t* d_reads,
                         const uint8_t* d_contigs, int32_t* d_scores, hipStream_t stream);
 uint32_t full_score_max_rows();
@@ -84,6 +87,7 @@ struct stitch_ctx {
     // results of the last batch
     std::vector<stitch_read_result> rr; std::vector<stitch_chain> chains; std::vector<stitch_op> ops;
     uint8_t* pin = nullptr;                       // pinned staging buffer for result downloads (PIN_BYTES)
+    uint16_t* pin_bands[2] = {nullptr, nullptr}; size_t pin_bands_elems = 0;   // pinned band staging of the pre-alignment pipeline (two chunks)
     std::vector<std::vector<HAln>> job_chains;   // final chains per job (a run of identical reads shares one job)
     std::vector<long> per_read;                  // read -> index into job_chains, -1 = none; for stitch_format_sam
     stitch_timing tm{};
@@ -185,6 +189,7 @@ void stitch_ctx_destroy(stitch_ctx* c) {
     void* ptrs[] = {c->d_xseq, c->d_S0, c->d_Slen0, c->d_Sn0, c->d_SnSet0, c->d_Smove0, c->d_Imove0, c->d_lx0, c->d_base0, c->arena, c->pre_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->pin) (void)hipHostFree(c->pin);
+    for (auto* b : c->pin_bands) if (b) (void)hipHostFree(b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -377,7 +382,8 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             uint32_t tiles = 0; for (uint32_t a : jb.act) tiles += (c.al[a].m + 255) / 256;
             gd_min = std::min(gd_min, std::min(4u, std::max(1u, (tiles + 249u) / 250u)));
         }
-        const size_t win = all_fast ? std::min<size_t>(jobs.size(), (size_t)std::max(1, c.n_cus) / gd_min) : jobs.size();
+        // (reads that get ONE workgroup each do not wait for anybody, so any number of them shares a launch)
+        const size_t win = (all_fast && gd_min > 1) ? std::min<size_t>(jobs.size(), (size_t)std::max(1, c.n_cus) / gd_min) : jobs.size();
         size_t cur = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
             cur += lay[k].bytes + sizeof(JobView) + sizeof(WalkArgs) + 512;
@@ -435,9 +441,13 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             // about 250 tiles per workgroup, and more of them share a launch)
             const uint32_t g_des = std::min(4u, std::max(1u, (tiles + 249u) / 250u));
             max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, g_des));
+            // one workgroup per read: nothing waits across workgroups, so the launch may hold more reads than there are CUs
+            // (two or three such workgroups of a few waves share a CU and fill each other's per-column stalls)
+            if (std::max(g_min, g_des) == 1) max_jobs = 4096;
             if (const char* g = getenv("STITCH_WG_PER_READ")) max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, (uint32_t)std::max(1, atoi(g))));
         }
-        while (k1 < jobs.size() && used + lay[k1].bytes + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].bytes; ++k1; }
+        const size_t per_job = sizeof(JobView) + sizeof(WalkArgs) + 512;     // the launch's job table, after the jobs' own buffers
+        while (k1 < jobs.size() && used + lay[k1].bytes + per_job + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].bytes + per_job; ++k1; }
         if (k1 == k0) return fail(STITCH_ENOMEM, "arena too small for one job");
         const uint32_t nj = (uint32_t)(k1 - k0);
         std::vector<JobView> views(nj); std::vector<WalkArgs> wargs(nj);
@@ -636,11 +646,14 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
     const BandScoring sc{c.opts.match_score, c.opts.mismatch_score, c.opts.gap_open, c.opts.gap_extend};
     has.assign(jobs.size(), 0); score.assign(jobs.size(), 0);
     auto al256 = [](size_t v) { return (v + 255) / 256 * 256; };
-    size_t k0 = 0;
-    while (k0 < jobs.size()) {
-        // as many reads as the scratch buffer holds
+
+    // chunks of reads: as many as the device scratch holds, and at most PRE_CHUNK, so that a batch makes several chunks and
+    // the host stage of one (seeds, backbone, band: threads) overlaps the device stage of the one before
+    constexpr size_t PRE_CHUNK = 64;
+    std::vector<std::pair<size_t, size_t>> chunks;
+    for (size_t k0 = 0; k0 < jobs.size();) {
         size_t k1 = k0, bytes = 0;
-        while (k1 < jobs.size()) {
+        while (k1 < jobs.size() && k1 - k0 < PRE_CHUNK) {
             const size_t m = jobs[k1].y.size();
             if (m > 65534) return fail(STITCH_EINVAL, "pre_align: reads longer than 65534 bases are not supported");
             size_t need = al256(m);
@@ -649,14 +662,44 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
             bytes += need; ++k1;
         }
         if (k1 == k0) return fail(STITCH_ENOMEM, "pre_align: one read does not fit in the pre-alignment scratch (STITCH_PREALIGN_BYTES)");
-        const size_t nj = k1 - k0, np = nj * C;
-        std::vector<uint8_t> h_reads; std::vector<uint16_t> h_bands; std::vector<BandPair> pairs(np);
-        size_t state_elems = 0;
-        std::vector<uint32_t> full_ids, banded_ids; uint32_t full_max_m = 0;
+        chunks.push_back({k0, k1}); k0 = k1;
+    }
+
+    // Band layout of a chunk, fixed before any band is known so that the host threads write straight into the pinned
+    // staging buffer: pair (q, a) owns 2 (n_a + 1) uint16 at q * per_read + a_off[a] (a pair scored over the full matrix
+    // leaves its slot unused), and 3 (m_q + 1) int32 of device state at state_at[q] + a * 3 (m_q + 1).
+    std::vector<uint64_t> a_off(C + 1, 0);
+    for (uint32_t a = 0; a < C; ++a) a_off[a + 1] = a_off[a] + 2ull * (c.al[a].m + 1);
+    const uint64_t per_read = a_off[C];
+    {
+        size_t most = 0; for (auto& ch : chunks) most = std::max(most, ch.second - ch.first);
+        const size_t want = most * per_read;
+        if (want > c.pin_bands_elems) {
+            for (auto*& b : c.pin_bands) { if (b) { (void)hipHostFree(b); b = nullptr; } }
+            c.pin_bands_elems = 0;
+            for (auto*& b : c.pin_bands) HIP_TRY(hipHostMalloc((void**)&b, want * sizeof(uint16_t), hipHostMallocDefault));
+            c.pin_bands_elems = want;
+        }
+    }
+    struct Staged {                                   // what the host stage hands to the device stage
+        size_t k0 = 0, k1 = 0;
+        std::vector<uint8_t> h_reads; const uint16_t* bands = nullptr; size_t band_elems = 0; std::vector<BandPair> pairs;
+        std::vector<uint32_t> full_ids, banded_ids, tall_ids; uint32_t full_max_m = 0, banded_max_m = 0; size_t state_elems = 0;   // banded = LDS-ring kernel, tall = global-state kernel
+        double host_ms = 0;
+    };
+    auto host_stage = [&](size_t k0, size_t k1, uint16_t* bands, Staged& S) {
         auto t_h0 = std::chrono::steady_clock::now();
+        const size_t nj = k1 - k0, np = nj * C;
+        S.k0 = k0; S.k1 = k1; S.pairs.resize(np); S.bands = bands; S.band_elems = nj * per_read;
+        std::vector<uint64_t> q_off(nj), state_at(nj);
+        for (size_t q = 0; q < nj; ++q) {
+            const Job& jb = jobs[k0 + q];
+            q_off[q] = S.h_reads.size(); S.h_reads.insert(S.h_reads.end(), jb.y.begin(), jb.y.end());
+            state_at[q] = S.state_elems; S.state_elems += (size_t)C * 3ull * (jb.y.size() + 1);
+        }
+        std::vector<uint8_t> full(np, 0);                     // 1 = full matrix, 2 = a band column taller than the LDS ring
+        const uint32_t ring = banded_ring_rows();
         // seeds, backbone and band of every pair: independent per read, so the reads are dealt to host threads
-        struct PerRead { std::vector<uint16_t> bands; std::vector<uint64_t> band_at; std::vector<uint8_t> full; };
-        std::vector<PerRead> pr(nj);
         {
             const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({nj, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16}));
             std::atomic<size_t> next{0};
@@ -664,55 +707,57 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
                 std::vector<uint16_t> lo_, hi_; std::vector<std::vector<Seed>> seeds_;
                 for (;;) {
                     const size_t q = next.fetch_add(1); if (q >= nj) break;
-                    const Job& jb = jobs[k0 + q]; PerRead& R = pr[q];
-                    R.band_at.assign(C, 0); R.full.assign(C, 0);
-                    find_seeds(c.kidx, c.h_xseq.data(), c.strands, jb.y.data(), (uint32_t)jb.y.size(), seeds_);
+                    const Job& jb = jobs[k0 + q];
+                    const uint32_t m = (uint32_t)jb.y.size();
+                    find_seeds(c.kidx, c.h_xseq.data(), c.strands, jb.y.data(), m, seeds_);
                     for (uint32_t a = 0; a < C; ++a) {
-                        const bool full = make_band(seeds_[a], (uint32_t)jb.y.size(), c.al[a].m, (uint32_t)c.opts.kmer_size, (uint32_t)c.opts.band_width,
-                                                    c.opts.match_score, c.opts.gap_open, c.opts.gap_extend, lo_, hi_);
-                        if (full && jb.y.size() <= full_score_max_rows()) { R.full[a] = 1; continue; }                 // LDS kernel: no band needed
-                        R.band_at[a] = R.bands.size();
-                        R.bands.insert(R.bands.end(), lo_.begin(), lo_.end()); R.bands.insert(R.bands.end(), hi_.begin(), hi_.end());
+                        const Aligner& A = c.al[a];
+                        BandPair& P = S.pairs[q * C + a];
+                        P.m = m; P.n = A.m; P.q_off = q_off[q]; P.t_off = A.seqoff; P.band_off = 0; P.state_off = 0;
+                        const bool is_full = make_band(seeds_[a], m, A.m, (uint32_t)c.opts.kmer_size, (uint32_t)c.opts.band_width,
+                                                       c.opts.match_score, c.opts.gap_open, c.opts.gap_extend, lo_, hi_);
+                        if (is_full && m <= full_score_max_rows()) { full[q * C + a] = 1; continue; }                   // register / LDS kernel: no band needed
+                        P.band_off = q * per_read + a_off[a];
+                        P.state_off = state_at[q] + (uint64_t)a * 3ull * (m + 1);
+                        for (uint32_t col = 0; col <= A.m; ++col) if (hi_[col] > lo_[col] && (uint32_t)(hi_[col] - lo_[col]) > ring) { full[q * C + a] = 2; break; }
+                        memcpy(bands + P.band_off, lo_.data(), sizeof(uint16_t) * (A.m + 1));
+                        memcpy(bands + P.band_off + A.m + 1, hi_.data(), sizeof(uint16_t) * (A.m + 1));
                     }
                 }
             };
             std::vector<std::thread> pool; for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
             work(); for (auto& th : pool) th.join();
         }
-        for (size_t q = 0; q < nj; ++q) {
-            const Job& jb = jobs[k0 + q];
-            const uint64_t q_off = h_reads.size(), b_off = h_bands.size();
-            h_reads.insert(h_reads.end(), jb.y.begin(), jb.y.end());
-            h_bands.insert(h_bands.end(), pr[q].bands.begin(), pr[q].bands.end());
-            for (uint32_t a = 0; a < C; ++a) {
-                const Aligner& A = c.al[a];
-                BandPair& P = pairs[q * C + a];
-                P.m = (uint32_t)jb.y.size(); P.n = A.m; P.q_off = q_off; P.t_off = A.seqoff; P.band_off = 0; P.state_off = 0;
-                if (pr[q].full[a]) { full_ids.push_back((uint32_t)(q * C + a)); full_max_m = std::max(full_max_m, P.m); continue; }
-                banded_ids.push_back((uint32_t)(q * C + a));
-                P.band_off = b_off + pr[q].band_at[a];
-                P.state_off = state_elems; state_elems += 3ull * (P.m + 1);
-            }
-            pr[q] = PerRead();
+        for (size_t k = 0; k < np; ++k) {
+            if (full[k] == 1) { S.full_ids.push_back((uint32_t)k); S.full_max_m = std::max(S.full_max_m, S.pairs[k].m); }
+            else if (full[k] == 2) S.tall_ids.push_back((uint32_t)k);
+            else { S.banded_ids.push_back((uint32_t)k); S.banded_max_m = std::max(S.banded_max_m, S.pairs[k].m); }
         }
+        S.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
+    };
+    auto device_stage = [&](Staged& S) -> int {
+        const size_t k0 = S.k0, nj = S.k1 - S.k0, np = nj * C;
         uint8_t* p = c.pre_buf;
-        uint8_t* d_reads = p; p += al256(h_reads.size());
-        uint16_t* d_bands = (uint16_t*)p; p += al256(h_bands.size() * 2);
+        uint8_t* d_reads = p; p += al256(S.h_reads.size());
+        uint16_t* d_bands = (uint16_t*)p; p += al256(S.band_elems * 2);
         BandPair* d_pairs = (BandPair*)p; p += al256(np * sizeof(BandPair));
         int32_t* d_scores = (int32_t*)p; p += al256(np * 4);
-        uint32_t* d_full = (uint32_t*)p; p += al256(full_ids.size() * 4);
-        uint32_t* d_banded = (uint32_t*)p; p += al256(banded_ids.size() * 4);
-        int32_t* d_state = (int32_t*)p; p += al256(state_elems * 4);
+        uint32_t* d_full = (uint32_t*)p; p += al256(S.full_ids.size() * 4);
+        uint32_t* d_banded = (uint32_t*)p; p += al256(S.banded_ids.size() * 4);
+        uint32_t* d_tall = (uint32_t*)p; p += al256(S.tall_ids.size() * 4);
+        int32_t* d_state = (int32_t*)p; p += al256(S.state_elems * 4);
         if ((size_t)(p - c.pre_buf) > c.pre_bytes) return fail(STITCH_EINTERNAL, "pre-alignment scratch overflow");
-        c.tm.prealign_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
         auto t_k0 = std::chrono::steady_clock::now();
-        HIP_TRY(hipMemcpyAsync(d_reads, h_reads.data(), h_reads.size(), hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(hipMemcpyAsync(d_bands, h_bands.data(), h_bands.size() * 2, hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(hipMemcpyAsync(d_pairs, pairs.data(), np * sizeof(BandPair), hipMemcpyHostToDevice, c.stream));
-        if (!full_ids.empty()) HIP_TRY(hipMemcpyAsync(d_full, full_ids.data(), full_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
-        if (!banded_ids.empty()) HIP_TRY(hipMemcpyAsync(d_banded, banded_ids.data(), banded_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
-        launch_banded_scores(d_pairs, d_banded, (uint32_t)banded_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream);
-        launch_full_scores(d_pairs, d_full, (uint32_t)full_ids.size(), full_max_m, sc, d_reads, c.d_xseq, d_scores, c.stream);
+        HIP_TRY(hipMemcpyAsync(d_reads, S.h_reads.data(), S.h_reads.size(), hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemcpyAsync(d_bands, S.bands, S.band_elems * 2, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemcpyAsync(d_pairs, S.pairs.data(), np * sizeof(BandPair), hipMemcpyHostToDevice, c.stream));
+        if (!S.full_ids.empty()) HIP_TRY(hipMemcpyAsync(d_full, S.full_ids.data(), S.full_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
+        if (!S.banded_ids.empty()) HIP_TRY(hipMemcpyAsync(d_banded, S.banded_ids.data(), S.banded_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
+        if (!S.tall_ids.empty()) HIP_TRY(hipMemcpyAsync(d_tall, S.tall_ids.data(), S.tall_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
+        if (getenv("STITCH_BANDED_GLOBAL") || !launch_banded_scores_lds(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream))
+            launch_banded_scores(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream);
+        launch_banded_scores(d_pairs, d_tall, (uint32_t)S.tall_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream);
+        launch_full_scores(d_pairs, d_full, (uint32_t)S.full_ids.size(), S.full_max_m, sc, d_reads, c.d_xseq, d_scores, c.stream);
         HIP_TRY(hipGetLastError());
         std::vector<int32_t> sco(np);
         HIP_TRY(hipMemcpyAsync(sco.data(), d_scores, np * 4, hipMemcpyDeviceToHost, c.stream));
@@ -733,9 +778,35 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
             has[k0 + q] = any ? 1 : 0; score[k0 + q] = best;
             if (any && c.opts.pre_align_subset_contigs) { std::sort(kept.begin(), kept.end()); jb.act = kept; }
         }
-        k0 = k1;
+        return STITCH_OK;
+    };
+
+    // two-stage pipeline: a producer thread stages chunk i + 1 on the host while this thread runs chunk i on the device
+    // (the host stage reads jobs[].y only; the device stage writes jobs[].act of ITS chunk only)
+    std::vector<Staged> staged(chunks.size());
+    std::vector<std::atomic<int>> ready(chunks.size());
+    for (auto& r : ready) r.store(0);
+    std::atomic<size_t> consumed{0};
+    std::atomic<bool> stop{false};
+    std::thread producer([&]() {
+        for (size_t i = 0; i < chunks.size() && !stop.load(); ++i) {
+            while (i > consumed.load() + 1 && !stop.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));   // two staging buffers: chunk i reuses the one of chunk i - 2
+            try { host_stage(chunks[i].first, chunks[i].second, c.pin_bands[i & 1], staged[i]); ready[i].store(1, std::memory_order_release); }
+            catch (...) { ready[i].store(-1, std::memory_order_release); return; }              // out of host memory
+        }
+    });
+    int rc = STITCH_OK;
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        while (!ready[i].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        if (ready[i].load() < 0) { rc = fail(STITCH_ENOMEM, "pre_align: out of host memory while building the bands"); break; }
+        c.tm.prealign_host_ms += staged[i].host_ms;
+        rc = device_stage(staged[i]);
+        staged[i] = Staged();
+        consumed.store(i + 1);
+        if (rc) { stop.store(true); break; }
     }
-    return STITCH_OK;
+    producer.join();
+    return rc;
 }
 
 // traceback_all's selection loop over per-end-contig candidate chains (traceback/mod.rs:152-217)

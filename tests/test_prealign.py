@@ -185,3 +185,31 @@ def test_banded_kernel_wide_bands_and_long_targets():
                 assert got[k][1] == o.prealign_score(), (w, k)
     finally:
         del os.environ["STITCH_PREALIGN_BYTES"]
+
+
+@pytest.mark.gpu
+def test_banded_kernels_agree_ring_tall_and_global(monkeypatch):
+    """the LDS-ring kernel, the global-state kernel it replaces (STITCH_BANDED_GLOBAL) and the oracle give the same scores:
+    w = 20 gives columns of one or two 64-row blocks, w = 200 of several, and w = 300 makes columns taller than the ring
+    (1201 > 1024 rows for the first read), which must take the global-state kernel"""
+    import stitch_amd
+    rng = random.Random(17)
+    t0, t1 = rnd(rng, 2600), rnd(rng, 900)
+    targets = [("a", t0), ("b", t1)]
+    reads = [t0[100:1100] + rnd(rng, 1500) + t0[1100:2300],                  # query gap of 1500: a tall column
+             mutate(rng, t0[50:2500], 0.04, 0.03, 0.03),
+             t1[20:880], mutate(rng, t1, 0.08, 0.04, 0.04) + rnd(rng, 200), rnd(rng, 500)]
+    for w in (20, 200, 300):
+        kw = dict(pre_align=True, pre_align_min_score=1, kmer_size=10, band_width=w, double_strand=True)
+        o = orc.Aligners(targets, **kw)
+        want = []
+        for read in reads:
+            o.align(read)
+            want.append(o.prealign_score())
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("STITCH_BANDED_GLOBAL", env)
+            else:
+                monkeypatch.delenv("STITCH_BANDED_GLOBAL", raising=False)
+            al = stitch_amd.Builder(**kw).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in targets], device=0)
+            assert [g[1] for g in al.align(reads)] == want, (w, env)
