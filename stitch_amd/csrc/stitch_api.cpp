@@ -76,7 +76,8 @@ struct stitch_ctx {
     std::vector<TargetInfo> targets;
     std::vector<Aligner> al;
     uint32_t C = 0, T = 0, RtotT = 0, max_m = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the banded kernel, concurrent with the full-matrix kernel
+    hipEvent_t ev2[2] = {nullptr, nullptr};
     // device, context lifetime
     uint8_t* d_xseq = nullptr; int32_t* d_S0 = nullptr; uint32_t* d_Slen0 = nullptr; int32_t* d_Sn0 = nullptr;
     uint8_t* d_SnSet0 = nullptr; uint8_t* d_Smove0 = nullptr; uint8_t* d_Imove0 = nullptr; uint32_t* d_lx0 = nullptr;
@@ -191,6 +192,8 @@ void stitch_ctx_destroy(stitch_ctx* c) {
     if (c->pin) (void)hipHostFree(c->pin);
     for (auto* b : c->pin_bands) if (b) (void)hipHostFree(b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev2) if (e) (void)hipEventDestroy(e);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -270,6 +273,8 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
         (rc = upload(&c->d_lx0, lx0)) || (rc = upload(&c->d_base0, base0))) return rc;
     { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal)); c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
     HIP_TRY(hipStreamCreate(&c->stream));
+    HIP_TRY(hipStreamCreate(&c->stream2));
+    for (auto& e : c->ev2) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     if (o->pre_align) {
         c->h_xseq = xseq;
@@ -754,10 +759,16 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         if (!S.full_ids.empty()) HIP_TRY(hipMemcpyAsync(d_full, S.full_ids.data(), S.full_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
         if (!S.banded_ids.empty()) HIP_TRY(hipMemcpyAsync(d_banded, S.banded_ids.data(), S.banded_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
         if (!S.tall_ids.empty()) HIP_TRY(hipMemcpyAsync(d_tall, S.tall_ids.data(), S.tall_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
-        if (getenv("STITCH_BANDED_GLOBAL") || !launch_banded_scores_lds(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream))
-            launch_banded_scores(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream);
-        launch_banded_scores(d_pairs, d_tall, (uint32_t)S.tall_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream);
+        // the banded kernels (latency-bound, one wavefront per pair) run on a second stream, concurrently with the full-matrix
+        // kernel (arithmetic-bound): both read the uploads above and write disjoint scores
+        HIP_TRY(hipEventRecord(c.ev2[0], c.stream));
+        HIP_TRY(hipStreamWaitEvent(c.stream2, c.ev2[0], 0));
+        if (getenv("STITCH_BANDED_GLOBAL") || !launch_banded_scores_lds(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream2))
+            launch_banded_scores(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream2);
+        launch_banded_scores(d_pairs, d_tall, (uint32_t)S.tall_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream2);
+        HIP_TRY(hipEventRecord(c.ev2[1], c.stream2));
         launch_full_scores(d_pairs, d_full, (uint32_t)S.full_ids.size(), S.full_max_m, sc, d_reads, c.d_xseq, d_scores, c.stream);
+        HIP_TRY(hipStreamWaitEvent(c.stream, c.ev2[1], 0));
         HIP_TRY(hipGetLastError());
         std::vector<int32_t> sco(np);
         HIP_TRY(hipMemcpyAsync(sco.data(), d_scores, np * 4, hipMemcpyDeviceToHost, c.stream));
