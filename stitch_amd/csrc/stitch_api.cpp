@@ -388,6 +388,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             gd_min = std::min(gd_min, std::min(4u, std::max(1u, (tiles + 249u) / 250u)));
         }
         // (reads that get ONE workgroup each do not wait for anybody, so any number of them shares a launch)
+        if (const char* g = getenv("STITCH_WG_PER_READ")) gd_min = (uint32_t)std::max(1, atoi(g));          // (experiments)
         const size_t win = (all_fast && gd_min > 1) ? std::min<size_t>(jobs.size(), (size_t)std::max(1, c.n_cus) / gd_min) : jobs.size();
         size_t cur = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
