@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads-per-step", type=int, default=64, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--contigs", type=int, default=50)

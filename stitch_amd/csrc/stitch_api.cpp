@@ -342,7 +342,10 @@ bool local16_ok(const stitch_ctx& c, const Job& jb) {
 }
 
 constexpr int MAX_WAVES_GENERIC = 8;               // fill_kernel.hip: __launch_bounds__(512)
-constexpr int MAX_WAVES_LOCAL = 12;                // fill_local16.hip: __launch_bounds__(768)
+#ifndef STITCH_LB
+#define STITCH_LB 768
+#endif
+constexpr int MAX_WAVES_LOCAL = STITCH_LB / 64;       // fill_local16.hip: __launch_bounds__(STITCH_LB), 12 waves
 
 int pick_waves(uint32_t nact, int maxw) {          // fewest rounds of contigs per column, then fewest waves
     if (const char* e = getenv("STITCH_MAX_WAVES")) maxw = std::max(1, std::min(maxw, atoi(e)));
