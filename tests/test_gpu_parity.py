@@ -20,7 +20,8 @@ MODE = {"local": "local", "querylocal": "query-local", "targetlocal": "target-lo
 
 
 def rc(seq):
-    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    comp = dict(zip("AGCTYRWSKMDVHBN", "TCGARYWSMKHBDVN"))               # util/dna.rs:5-8
+    comp.update({a.lower(): b.lower() for a, b in list(comp.items())})
     return "".join(comp[c] for c in reversed(seq))
 
 
@@ -236,6 +237,18 @@ def test_cfg5_shape_many_circular_contigs_suboptimal():
     reads = [r.decode() for r in synth.make_reads(db, 5, 600, 47, sub=0.01, ins=0.005, dele=0.005, circular=True)]
     run_pair(targets, reads, circular=True, suboptimal=True)
     run_pair(targets[:120], reads[:2], circular=True, suboptimal=True, double_strand=True, check_sam=False)   # 240 contig-strands (255 is the reference's limit)
+
+
+def test_iupac_codes_n_and_lower_case():
+    """bases are compared as bytes after upper-casing (N matches N, R matches R: `MatchParams`, util/dna.rs:5-23), the
+    reverse strand complements IUPAC codes (dna.rs:31-41); SAM text included (SEQ of reverse-strand records)"""
+    rng = random.Random(77)
+    targets = [(f"t{k}", rand_seq(rng, n, "ACGTNRYKMSWBDHV")) for k, n in enumerate([300, 520, 45])]
+    targets[1] = (targets[1][0], targets[1][1].lower())
+    reads = [chimera(rng, targets, rng.randint(40, 400), both=True) for _ in range(6)]
+    reads += [rc(targets[0][1][20:250]), "N" * 30 + targets[2][1] + "n" * 12, targets[1][1][100:400].upper()]
+    run_pair(targets, reads, double_strand=True)
+    run_pair(targets, reads[:4], double_strand=True, suboptimal=True, soft_clip=True, use_eq_and_x=True)
 
 
 def test_error_behaviour_matches_the_reference():
