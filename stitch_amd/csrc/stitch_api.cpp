@@ -88,6 +88,7 @@ struct stitch_ctx {
     // results of the last batch
     std::vector<stitch_read_result> rr; std::vector<stitch_chain> chains; std::vector<stitch_op> ops;
     uint8_t* pin = nullptr;                       // pinned staging buffer for result downloads (PIN_BYTES)
+    uint8_t* pin_h2d = nullptr; size_t pin_h2d_bytes = 0;   // pinned staging of a launch's per-job inputs
     uint16_t* pin_bands[2] = {nullptr, nullptr}; size_t pin_bands_elems = 0;   // pinned band staging of the pre-alignment pipeline (two chunks)
     std::vector<std::vector<HAln>> job_chains;   // final chains per job (a run of identical reads shares one job)
     std::vector<long> per_read;                  // read -> index into job_chains, -1 = none; for stitch_format_sam
@@ -190,6 +191,7 @@ void stitch_ctx_destroy(stitch_ctx* c) {
     void* ptrs[] = {c->d_xseq, c->d_S0, c->d_Slen0, c->d_Sn0, c->d_SnSet0, c->d_Smove0, c->d_Imove0, c->d_lx0, c->d_base0, c->arena, c->pre_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin_h2d) (void)hipHostFree(c->pin_h2d);
     for (auto* b : c->pin_bands) if (b) (void)hipHostFree(b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev2) if (e) (void)hipEventDestroy(e);
@@ -463,6 +465,16 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         std::vector<size_t> base(nj);
         int waves = 1;
         auto t_h2d0 = std::chrono::steady_clock::now();
+        // the small per-job inputs (read, active contigs, opposite strands, contig table) are contiguous in a job's block:
+        // they are assembled in one pinned buffer and go up with one copy per job, without a synchronisation in between
+        std::vector<size_t> stage_at(nj + 1, 0);
+        for (uint32_t q = 0; q < nj; ++q) stage_at[q + 1] = stage_at[q] + (lay[k0 + q].off_hdr - lay[k0 + q].off_y);
+        if (stage_at[nj] > c.pin_h2d_bytes) {
+            if (c.pin_h2d) { (void)hipHostFree(c.pin_h2d); c.pin_h2d = nullptr; c.pin_h2d_bytes = 0; }
+            const size_t want_b = std::max<size_t>(stage_at[nj] * 3 / 2, (size_t)1 << 20);
+            HIP_TRY(hipHostMalloc((void**)&c.pin_h2d, want_b, hipHostMallocDefault));
+            c.pin_h2d_bytes = want_b;
+        }
         size_t o = 0;
         for (uint32_t q = 0; q < nj; ++q) {
             const Job& jb = jobs[k0 + q]; const JobLayout& L = lay[k0 + q];
@@ -480,11 +492,12 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
                 // the opposite strand only counts when it is part of the current subset (multi_contig_aligner.rs:241-262)
                 if (isact[a] && c.al[a].opp >= 0 && isact[c.al[a].opp]) opp[a] = c.al[a].opp;
             }
-            HIP_TRY(hipMemcpyAsync(B + L.off_y, jb.y.data(), L.n, hipMemcpyHostToDevice, c.stream));
-            HIP_TRY(hipMemcpyAsync(B + L.off_act, jb.act.data(), 4ull * L.nact, hipMemcpyHostToDevice, c.stream));
-            HIP_TRY(hipMemcpyAsync(B + L.off_opp, opp.data(), 4ull * c.C, hipMemcpyHostToDevice, c.stream));
-            HIP_TRY(hipMemcpyAsync(B + L.off_cd, cd.data(), sizeof(ContigDesc) * (size_t)c.C, hipMemcpyHostToDevice, c.stream));
-            HIP_TRY(hipStreamSynchronize(c.stream));            // cd/opp are stack vectors
+            uint8_t* stg = c.pin_h2d + stage_at[q];
+            memcpy(stg, jb.y.data(), L.n);
+            memcpy(stg + (L.off_act - L.off_y), jb.act.data(), 4ull * L.nact);
+            memcpy(stg + (L.off_opp - L.off_y), opp.data(), 4ull * c.C);
+            memcpy(stg + (L.off_cd - L.off_y), cd.data(), sizeof(ContigDesc) * (size_t)c.C);
+            HIP_TRY(hipMemcpyAsync(B + L.off_y, stg, L.off_hdr - L.off_y, hipMemcpyHostToDevice, c.stream));
             JobView& V = views[q];
             V.tb_keyfmt = fast ? 1u : 0u;
             V.P = c.P; V.n = L.n; V.C = c.C; V.nact = L.nact; V.Rtot = L.Rj;
