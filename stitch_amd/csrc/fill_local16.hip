@@ -377,7 +377,7 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
 #ifndef STITCH_LB
 #define STITCH_LB 768          // 12 waves per workgroup: <= 168 VGPRs, 3 waves per SIMD (MAX_WAVES in stitch_api.cpp)
 #endif
-__global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* __restrict__ jobs, FillShared sh, uint32_t G) {
+__global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* __restrict__ jobs, FillShared sh, uint32_t G, uint32_t slots_cap) {
     const JobView& V = jobs[blockIdx.x / G];
     const uint32_t part = blockIdx.x % G;
     const DpParams P = V.P;
@@ -393,7 +393,8 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     __shared__ uint32_t s_abort;
     __shared__ int32_t s_carry[MAXC][12];             // carries handed from the wave that starts a contig to the one that ends it
     __shared__ uint32_t s_cflag[MAXC];                // (column << 8 | piece) for which s_carry[c] is valid
-    __shared__ u32x4 s_slots[MAXSLOTS];               // {contig | tile<<8 | flags, state row of the tile, base offset of the tile, -}
+    extern __shared__ u32x4 s_slots[];                // [slots_cap] {contig | tile<<8 | flags, state row of the tile, base offset of the tile, -}:
+                                                      // sized by the launch (<= MAXSLOTS), so that small jobs leave LDS for more workgroups per CU
     __shared__ uint32_t s_wbeg[16], s_wend[16];
     __shared__ uint32_t s_hwid[16], s_bnd[17];
     __shared__ uint32_t s_m[MAXC], s_roff[MAXC], s_seq[MAXC];
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
         s_bnd[W] = wsum;
         uint32_t NT = 0;
         for (uint32_t k = part; k < nact; k += G) NT += (V.cd[V.act[k]].m + TILE - 1) / TILE;
-        if (NT > MAXSLOTS) NT = MAXSLOTS;                     // (the host keeps NT within the table)
+        if (NT > slots_cap) NT = slots_cap;                   // (the host sizes the table for the launch's largest workgroup)
         // weights -> tile boundaries.  No wave of the first min(W, NT) may get an empty range: a contig's pieces are numbered
         // by consecutive waves, and a wave waits for the piece number before its own (an empty range in between would never
         // publish it).
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
                 uint32_t k2 = kk, t = t0;
                 for (uint32_t x = lo; x < to; ++x) {
                     const uint32_t c = V.act[k2]; const uint32_t nt = (V.cd[c].m + TILE - 1) / TILE;
-                    if (x >= from && ns < MAXSLOTS) {
+                    if (x >= from && ns < slots_cap) {
                         u32x4 rec;
                         rec.x = c | (t << 8) | (t == 0 ? SLOT_FIRST : 0u) | (t + 1 == nt ? SLOT_LAST : 0u) |
                                 ((x == lo && t != 0) ? SLOT_CIN : 0u) | ((x + 1 == hi && t + 1 != nt) ? SLOT_COUT : 0u);
@@ -765,8 +766,10 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
 #endif
 }
 
-void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, const FillShared& sh, hipStream_t stream) {
-    hipLaunchKernelGGL(fill_local16_kernel, dim3(n_jobs * G), dim3(waves * 64), 0, stream, d_jobs, sh, G);
+uint32_t fill_local16_max_slots() { return MAXSLOTS; }
+void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, uint32_t slots_cap, const FillShared& sh, hipStream_t stream) {
+    slots_cap = slots_cap < 16u ? 16u : slots_cap > MAXSLOTS ? MAXSLOTS : slots_cap;
+    hipLaunchKernelGGL(fill_local16_kernel, dim3(n_jobs * G), dim3(waves * 64), sizeof(u32x4) * (size_t)slots_cap, stream, d_jobs, sh, G, slots_cap);
 }
 
 }  // namespace stitch

@@ -43,7 +43,7 @@ void launch_fill(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillSh
 void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, uint32_t max_nact_mode1, hipStream_t stream);
 constexpr size_t PIN_BYTES = (size_t)64 << 20;   // pinned staging buffer for result downloads
 constexpr uint32_t TILE_ROWS = 512;   // 64 lanes x 8 rows (Local-mode kernel; the generic one uses 256): contig row blocks are padded to this
-void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, const FillShared& sh, hipStream_t stream);
+void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, uint32_t slots_cap, const FillShared& sh, hipStream_t stream);
 }  // namespace stitch
 
 using namespace stitch;
@@ -556,7 +556,14 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             if (const char* e = getenv("STITCH_MAX_WAVES")) waves = std::max(1, std::min(waves, atoi(e)));
         }
         c.tm_wg_per_read = G;
-        if (fast) launch_fill_local16(d_views, nj, G, waves, sh, c.stream);
+        uint32_t slots_cap = 0;                          // tiles of the launch's largest workgroup (contigs are dealt round-robin to a read's G workgroups)
+        if (fast) for (uint32_t q = 0; q < nj; ++q) {
+            std::vector<uint32_t> per(G, 0);
+            const std::vector<uint32_t>& act = jobs[k0 + q].act;
+            for (size_t k = 0; k < act.size(); ++k) per[k % G] += (c.al[act[k]].m + 255) / 256;
+            for (uint32_t v : per) slots_cap = std::max(slots_cap, v);
+        }
+        if (fast) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, c.stream);
         else launch_fill(d_views, nj, waves, sh, c.stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev[1], c.stream));
