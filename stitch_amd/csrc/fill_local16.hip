@@ -268,9 +268,6 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
     // some row does the wave redo the rows with the full merge.
     int32_t Fo[R]; uint32_t code[R]; uint32_t tk = 0;
     bool merge = LASTCOL;                      // (the last column also stores the insertion values of every row)
-    bool c2row[R];
-#pragma unroll
-    for (int u = 0; u < R; ++u) c2row[u] = true;
     if (!LASTCOL) {
         int32_t rk = run.key; bool c2any = false;
 #pragma unroll
@@ -280,8 +277,7 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
             rk = ext ? rk : el[u].key;
             const int32_t bi = rk + LK.giL + K.ge * u;
             const int32_t biw = (int32_t)((uint32_t)bi << 16);                     // only looked at when 0 <= bi (<= 32767)
-            c2row[u] = bi >= 0 && biw > ra[u].bs2h && (biw | 0xFFFF) >= ra[u].JW;
-            c2any |= c2row[u];
+            c2any |= bi >= 0 && biw > ra[u].bs2h && (biw | 0xFFFF) >= ra[u].JW;
         }
         merge = __ballot(c2any) != 0ull;
 #ifdef STITCH_PROFILE
@@ -308,10 +304,8 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
         if (!ext) run = el[u];
         const int32_t bi = run.key + LK.giL + K.ge * u;
         const uint32_t il = (uint32_t)(run.q + (int32_t)LK.iL + u);
-        // the merge changes a row only where some lane of the wave saw c2 && !c5 in it (see above): the other rows of the
-        // tile keep phase A's result
-        uint32_t mv = ra[u].mvT; int32_t F = ra[u].T;
-        if (LASTCOL || __ballot(c2row[u]) != 0ull) F = row_phase_c_word(ra[u], bi, il, mv);
+        uint32_t mv;
+        const int32_t F = row_phase_c_word(ra[u], bi, il, mv);
         code[u] = mv | (ext ? TBB_IEXT : 0u) | (ra[u].dext ? TBB_DEXT : 0u);
         Fo[u] = F;
         if (!PARTIAL || i < m) tk = (uint32_t)F > tk ? (uint32_t)F : tk;               // the lane's largest S word of this tile (F >= 0)
