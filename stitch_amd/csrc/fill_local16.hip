@@ -284,38 +284,36 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
         wc.n_tiles += 1; wc.n_merge += merge ? 1u : 0u; wc.n_c2 += (uint32_t)__popcll(__ballot(c2any));
 #endif
     }
-    if (!merge) {
+    // default: phase A's result; the merge, where it runs, overwrites it in place (no copies where the two paths join)
+    uint32_t mvo[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) { Fo[u] = ra[u].T; mvo[u] = ra[u].mvT; }
+    if (merge) {
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            const uint32_t i = i0 + u;
-            const int32_t F = ra[u].T; const uint32_t mv = ra[u].mvT;
-            code[u] |= mv; Fo[u] = F;
-            if (!PARTIAL || i < m) tk = (uint32_t)F > tk ? (uint32_t)F : tk;
-            if (PARTIAL) {
-                if (i == m) { rm.F = F; rm.mv = mv; rm.bits = code[u] & (TBB_IEXT | TBB_DEXT); rm.BD = ra[u].BD; rm.DG = ra[u].DG; }
-                if (i > m) { Fo[u] = 0; ra[u].BD = word_make(-16384, 0); code[u] = 0; }
+            const uint32_t ext = run.key >= el[u].key ? 1u : 0u;
+            if (!ext) run = el[u];
+            const int32_t bi = run.key + LK.giL + K.ge * u;
+            const uint32_t il = (uint32_t)(run.q + (int32_t)LK.iL + u);
+            uint32_t mv;
+            Fo[u] = row_phase_c_word(ra[u], bi, il, mv);
+            mvo[u] = mv;
+            if (LASTCOL) {                         // (before the last column the first pass has set these bits from the same chain)
+                code[u] = (ext ? TBB_IEXT : 0u) | (ra[u].dext ? TBB_DEXT : 0u);
+                if (!PARTIAL || i0 + u <= m) { const GPtrsCold& C = *V.cold; C.S[r + u] = word_score(Fo[u]); C.Slen[r + u] = word_len(Fo[u]); C.Ival[r + u] = bi; C.Ilen[r + u] = il; }
             }
+            ROW_FENCE
         }
-    } else {
+    }
 #pragma unroll
     for (int u = 0; u < R; ++u) {
         const uint32_t i = i0 + u;
-        const uint32_t ext = run.key >= el[u].key ? 1u : 0u;
-        if (!ext) run = el[u];
-        const int32_t bi = run.key + LK.giL + K.ge * u;
-        const uint32_t il = (uint32_t)(run.q + (int32_t)LK.iL + u);
-        uint32_t mv;
-        const int32_t F = row_phase_c_word(ra[u], bi, il, mv);
-        code[u] = mv | (ext ? TBB_IEXT : 0u) | (ra[u].dext ? TBB_DEXT : 0u);
-        Fo[u] = F;
-        if (!PARTIAL || i < m) tk = (uint32_t)F > tk ? (uint32_t)F : tk;               // the lane's largest S word of this tile (F >= 0)
+        code[u] |= mvo[u];
+        if (!PARTIAL || i < m) tk = (uint32_t)Fo[u] > tk ? (uint32_t)Fo[u] : tk;       // the lane's largest S word of this tile (F >= 0)
         if (PARTIAL) {
-            if (i == m) { rm.F = F; rm.mv = mv; rm.bits = code[u] & (TBB_IEXT | TBB_DEXT); rm.BD = ra[u].BD; rm.DG = ra[u].DG; }
+            if (i == m) { rm.F = Fo[u]; rm.mv = mvo[u]; rm.bits = code[u] & (TBB_IEXT | TBB_DEXT); rm.BD = ra[u].BD; rm.DG = ra[u].DG; }
             if (i > m) { Fo[u] = 0; ra[u].BD = word_make(-16384, 0); code[u] = 0; }
         }
-        if (LASTCOL) { if (!PARTIAL || i <= m) { const GPtrsCold& C = *V.cold; C.S[r + u] = word_score(F); C.Slen[r + u] = word_len(F); C.Ival[r + u] = bi; C.Ilen[r + u] = il; } }
-        ROW_FENCE
-    }
     }
     // Running records of the lane, updated per tile, not per row (rows ascend within a lane and across its tiles, so an equal
     // value never replaces an earlier one; after a contig's first tiles these branches are rarely taken):
