@@ -11,8 +11,6 @@ tag=${1:-r01_x}
 out=gpurun_out/collect_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; exit 1; }
-cp "$out/bench.json" "profiles/${tag}_bench_local16.json"
 rocprofv3 --kernel-trace --stats -d "$out/trace" -o run --output-format csv -- python3 bench.py --cpu-reads 0 > "$out/trace.log" 2>&1 || { echo "trace failed"; exit 1; }
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
   d="$out/pmc_$(echo $grp | tr ' ' '_' | cut -c1-40)"
@@ -20,4 +18,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VAL
   echo "pmc $grp done" >> "$out/progress.txt"
 done
 python3 profiles/summarize.py "$out" "$tag"
+# the bench line last: its roofline.traffic / roofline.valu figures read the PMC summary just written
+python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; exit 1; }
+cp "$out/bench.json" "profiles/${tag}_bench_local16.json"
 cp profiles/${tag}_* "$out/"        # gpurun merges only gpurun_out/ back: copy from there into profiles/ and commit
