@@ -755,6 +755,12 @@ __global__ __launch_bounds__(STITCH_LB) void fill_local16_kernel(const JobView* 
     if (lane == 0) { atomicAdd((unsigned long long*)(V.err + 4) + 120, pf_sum[2] >> 32); atomicAdd((unsigned long long*)(V.err + 4) + 121, pf_sum[2] & 0xFFFFFFFFull); }
     pf_sum[1] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8]
     if (lane == 0 && blockIdx.x == 0) { unsigned long long* o = (unsigned long long*)(V.err + 4) + wave * 8; for (int k = 0; k < 8; ++k) o[k] = pf_sum[k]; }
+    if (threadIdx.x == 0) {
+        unsigned long long* o = (unsigned long long*)(V.err + 4);
+        o[122] = wall_clock64();                                                           // when this read's (last-written) workgroup ended, 100 MHz
+        if (part < 32) { o[128 + 2 * part] = wall_clock64();                              // per workgroup: end time, placement (XCC_ID, HW_ID)
+                         o[129 + 2 * part] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
+    }
 #endif
 }
 

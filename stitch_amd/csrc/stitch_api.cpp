@@ -301,7 +301,8 @@ namespace {
 struct JobLayout {
     uint32_t n, nact, Rj, slots, ops_cap;
     size_t off_S, off_Slen, off_D, off_Dlen, off_Sn, off_SnLen, off_Ly, off_Ival, off_Ilen, off_SidxF, off_SfromF, off_SmoveF, off_ImoveF,
-        off_st16, off_xchg, off_tb, off_Lx, off_jti, off_jtf, off_Sm, off_Lm, off_y, off_act, off_opp, off_cd, off_hdr, off_ops, bytes;
+        off_st16, off_xchg, off_tb, off_Lx, off_jti, off_jtf, off_Sm, off_Lm, off_y, off_act, off_opp, off_cd, off_hdr, off_ops, bytes,
+        stride;              // distance to the next job's block in a launch (bytes rounded up to the launch's block alignment)
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -381,10 +382,24 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     std::vector<JobLayout> lay(jobs.size());
     size_t max_job = 0;
     for (size_t k = 0; k < jobs.size(); ++k) { lay[k] = layout_job(c, jobs[k]); max_job = std::max(max_job, lay[k].bytes); }
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = (size_t)(std::min(free_b + c.arena_bytes, total_b) * 0.90);
+    if (c.mem_limit) budget = std::min(budget, c.mem_limit);
+    if (max_job + (1 << 20) > budget) return fail(STITCH_ENOMEM, "one read needs " + std::to_string(max_job >> 20) + " MiB of device memory; only " + std::to_string(budget >> 20) + " MiB usable");
     // arena: as much of the free memory as useful, at least one job
     // (a launch never holds more jobs than there are compute units, so more than the largest such window is never used)
-    size_t want = 0;
-    {
+    // Job blocks start at multiples of a large power of two.  Measured (MI355X, cfg2, same box): with the blocks packed back
+    // to back the reads of a launch run at very different speeds depending on where their block starts (the slowest ends
+    // 170 ms after the fastest in a 585 ms launch, the same slots every time, whatever read or CUs they get); blocks at
+    // multiples of 1 GiB: 505 ms, 128 or 512 MiB: 541, 16 MiB: 695, 1 GiB + 256 KiB: 594.  So: the largest power of two
+    // (<= 1 GiB, <= the job size) that still lets the launch window fit the memory.
+    size_t want = 0, block_align = 256;
+    for (size_t a = (size_t)1 << 30; a >= 256; a >>= 1) {
+        if (a > max_job && a > 256) continue;
+        if (const char* e = getenv("STITCH_JOB_ALIGN")) { a = std::max<size_t>(256, (size_t)strtoull(e, nullptr, 10)); }      // (experiments)
+        for (size_t k = 0; k < jobs.size(); ++k) lay[k].stride = align_up(lay[k].bytes, a);
+        block_align = a; want = 0;
         // (the Local-mode kernel gives a read of T tiles min(4, ceil(T / 250)) workgroups, see the launch loop below)
         bool all_fast = true; uint32_t gd_min = 4;
         for (const Job& jb : jobs) {
@@ -397,17 +412,14 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         const size_t win = (all_fast && gd_min > 1) ? std::min<size_t>(jobs.size(), (size_t)std::max(1, c.n_cus) / gd_min) : jobs.size();
         size_t cur = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
-            cur += lay[k].bytes + sizeof(JobView) + sizeof(WalkArgs) + 512;
-            if (k >= win) cur -= lay[k - win].bytes + sizeof(JobView) + sizeof(WalkArgs) + 512;
+            cur += lay[k].stride + sizeof(JobView) + sizeof(WalkArgs) + 512;
+            if (k >= win) cur -= lay[k - win].stride + sizeof(JobView) + sizeof(WalkArgs) + 512;
             want = std::max(want, cur);
         }
         want += (size_t)2 << 20;
+        if (want + (1 << 20) <= budget || a == 256 || getenv("STITCH_JOB_ALIGN")) break;      // fits (or nothing smaller to try)
     }
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    size_t budget = (size_t)(std::min(free_b + c.arena_bytes, total_b) * 0.90);
-    if (c.mem_limit) budget = std::min(budget, c.mem_limit);
-    if (max_job + (1 << 20) > budget) return fail(STITCH_ENOMEM, "one read needs " + std::to_string(max_job >> 20) + " MiB of device memory; only " + std::to_string(budget >> 20) + " MiB usable");
+    if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] job blocks at multiples of %zu bytes, window %zu bytes\n", block_align, want);
     size_t arena_need = std::min(want + (1 << 20), budget);
     if (arena_need > c.arena_bytes) {
         if (c.arena) {
@@ -458,7 +470,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             if (const char* g = getenv("STITCH_WG_PER_READ")) max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, (uint32_t)std::max(1, atoi(g))));
         }
         const size_t per_job = sizeof(JobView) + sizeof(WalkArgs) + 512;     // the launch's job table, after the jobs' own buffers
-        while (k1 < jobs.size() && used + lay[k1].bytes + per_job + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].bytes + per_job; ++k1; }
+        while (k1 < jobs.size() && used + lay[k1].stride + per_job + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].stride + per_job; ++k1; }
         if (k1 == k0) return fail(STITCH_ENOMEM, "arena too small for one job");
         const uint32_t nj = (uint32_t)(k1 - k0);
         std::vector<JobView> views(nj); std::vector<WalkArgs> wargs(nj);
@@ -478,7 +490,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         size_t o = 0;
         for (uint32_t q = 0; q < nj; ++q) {
             const Job& jb = jobs[k0 + q]; const JobLayout& L = lay[k0 + q];
-            base[q] = o; uint8_t* B = c.arena + o; o += L.bytes;
+            base[q] = o; uint8_t* B = c.arena + o; o += L.stride;
             waves = std::max(waves, pick_waves(L.nact, MAX_WAVES_GENERIC));
             // per-job tables
             std::vector<ContigDesc> cd(c.C); std::vector<int32_t> opp(c.C, -1); std::vector<uint8_t> isact(c.C, 0);
@@ -521,8 +533,11 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         JobView* d_views = (JobView*)tail; tail += align_up(sizeof(JobView) * nj, 256);
         WalkArgs* d_wargs = (WalkArgs*)tail; tail += align_up(sizeof(WalkArgs) * nj, 256);
         if ((size_t)(tail - c.arena) > c.arena_bytes) return fail(STITCH_EINTERNAL, "arena overflow");
-        HIP_TRY(hipMemcpyAsync(d_views, views.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(hipMemcpyAsync(d_wargs, wargs.data(), sizeof(WalkArgs) * nj, hipMemcpyHostToDevice, c.stream));
+        // (experiment: STITCH_ROT rotates which workgroups serve which job, leaving the jobs' memory where it is)
+        std::vector<JobView> views_up = views; std::vector<WalkArgs> wargs_up = wargs;
+        if (const char* e = getenv("STITCH_ROT")) { const uint32_t rot = (uint32_t)atoi(e) % nj; std::rotate(views_up.begin(), views_up.begin() + rot, views_up.end()); std::rotate(wargs_up.begin(), wargs_up.begin() + rot, wargs_up.end()); }
+        HIP_TRY(hipMemcpyAsync(d_views, views_up.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemcpyAsync(d_wargs, wargs_up.data(), sizeof(WalkArgs) * nj, hipMemcpyHostToDevice, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
         c.tm.h2d_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h2d0).count();
 
@@ -582,7 +597,20 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         c.tm.launches += 1; c.tm.jobs += nj;
         if (getenv("STITCH_PROFILE_DUMP") && fast) {
             unsigned long long pf[128]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[0].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
-            for (uint32_t q = 0; q < nj; ++q) { unsigned long long tm2[2]; HIP_TRY(hipMemcpy(tm2, (const uint8_t*)views[q].err + 16 + 120 * 8, 16, hipMemcpyDeviceToHost)); fprintf(stderr, "[prof] job %u: tiles=%llu merged=%llu (%.1f%%)\n", q, tm2[0], tm2[1], 100.0 * tm2[1] / (tm2[0] ? tm2[0] : 1)); }
+            unsigned long long t_first = ~0ull;
+            std::vector<unsigned long long> t_end(nj);
+            for (uint32_t q = 0; q < nj; ++q) { unsigned long long tm2[3]; HIP_TRY(hipMemcpy(tm2, (const uint8_t*)views[q].err + 16 + 120 * 8, 24, hipMemcpyDeviceToHost)); t_end[q] = tm2[2]; t_first = std::min(t_first, tm2[2]);
+                fprintf(stderr, "[prof] job %u: tiles=%llu merged=%llu (%.1f%%)\n", q, tm2[0], tm2[1], 100.0 * tm2[1] / (tm2[0] ? tm2[0] : 1)); }
+            for (uint32_t q = 0; q < nj; ++q) {
+                unsigned long long w[64]; HIP_TRY(hipMemcpy(w, (const uint8_t*)views[q].err + 16 + 128 * 8, 16 * std::min(G, 32u), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[prof] place job %u:", q);
+                for (uint32_t p = 0; p < std::min(G, 32u); ++p) fprintf(stderr, " [end %.1f xcc %u se %u sh %u cu %u]", (double)(w[2 * p] - t_first) / 1e5, (unsigned)(w[2 * p + 1] >> 32) & 15u,
+                                                                         (unsigned)(w[2 * p + 1] >> 13) & 7u, (unsigned)(w[2 * p + 1] >> 12) & 1u, (unsigned)(w[2 * p + 1] >> 8) & 15u);
+                fprintf(stderr, "\n");
+            }
+            fprintf(stderr, "[prof] end of each read after the first to end, ms:");
+            for (uint32_t q = 0; q < nj; ++q) fprintf(stderr, " %.1f", (double)(t_end[q] - t_first) / 1e5);
+            fprintf(stderr, "\n");
             static const char* nm[8] = {"gather/loop", "select", "barrier1", "slot-setup", "tile", "finalize", "tile_wait", "barrier2"};
             for (int w = 0; w < waves; ++w) { fprintf(stderr, "[prof] wave %d:", w); for (int k = 0; k < 8; ++k) { if (k == 2) fprintf(stderr, " tiles=%llu merged=%llu", pf[w * 8 + 2] >> 32, pf[w * 8 + 2] & 0xFFFFFFFFull); else if (k == 1) fprintf(stderr, " simd=%u slot=%u cu=%u", (unsigned)((pf[w * 8 + 1] >> 4) & 3), (unsigned)(pf[w * 8 + 1] & 15), (unsigned)((pf[w * 8 + 1] >> 8) & 15)); else fprintf(stderr, " %s=%.1fM", nm[k], pf[w * 8 + k] / 1e6); } fprintf(stderr, "\n"); }
         }
