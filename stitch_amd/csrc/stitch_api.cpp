@@ -316,14 +316,19 @@ JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
     L.ops_cap = 2 * L.n + 2 * c.max_m + 64;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
-    L.off_S = take(4ull * R); L.off_Slen = take(4ull * R); L.off_D = take(4ull * R); L.off_Dlen = take(4ull * R);
+    // the arrays the fill kernel streams every column (row state, y-suffix records, traceback) start at multiples of 2 MiB in
+    // jobs that are large enough not to notice (measured on cfg2: 3-4 % over 256-byte packing; 4 KiB: nothing, 64 MiB: the same)
+    static const size_t big_env = [] { const char* e = getenv("STITCH_ARRAY_ALIGN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0; }();   // (experiments)
+    const size_t big_align = big_env ? big_env : (8ull * R >= ((size_t)1 << 20) ? (size_t)2 << 20 : (size_t)256);
+    auto take_big = [&](size_t bytes) { if (big_align > 256) o = align_up(o, big_align); return take(bytes); };
+    L.off_S = take(4ull * R); L.off_Slen = take(4ull * R); L.off_D = take_big(4ull * R); L.off_Dlen = take(4ull * R);
     if (L.off_Dlen != L.off_D + 4ull * R) abort();      // fill_local16.hip keeps its 8-byte y-suffix records in D..Dlen
     L.off_Sn = take(4ull * R); L.off_SnLen = take(4ull * R); L.off_Ly = take(4ull * R);
     L.off_Ival = take(4ull * R); L.off_Ilen = take(4ull * R); L.off_SidxF = take(4ull * R); L.off_SfromF = take(4ull * R);
     L.off_SmoveF = take(R); L.off_ImoveF = take(R);
-    L.off_st16 = take(8ull * R);
+    L.off_st16 = take_big(8ull * R);
     L.off_xchg = take(32ull * c.C + 4096);      // 2 parities x C contigs x two 8-byte granules, then the error word
-    L.off_tb = take((size_t)L.n * R);
+    L.off_tb = take_big((size_t)L.n * R);
     L.off_Lx = take(4ull * c.C * (L.n + 1)); L.off_jti = take(4ull * c.C * (L.n + 1)); L.off_jtf = take(4ull * c.C * (L.n + 1));
     L.off_Sm = take(4ull * c.C); L.off_Lm = take(4ull * c.C);
     L.off_y = take(L.n); L.off_act = take(4ull * L.nact); L.off_opp = take(4ull * c.C); L.off_cd = take(sizeof(ContigDesc) * (size_t)c.C);
