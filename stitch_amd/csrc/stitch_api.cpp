@@ -538,11 +538,8 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         JobView* d_views = (JobView*)tail; tail += align_up(sizeof(JobView) * nj, 256);
         WalkArgs* d_wargs = (WalkArgs*)tail; tail += align_up(sizeof(WalkArgs) * nj, 256);
         if ((size_t)(tail - c.arena) > c.arena_bytes) return fail(STITCH_EINTERNAL, "arena overflow");
-        // (experiment: STITCH_ROT rotates which workgroups serve which job, leaving the jobs' memory where it is)
-        std::vector<JobView> views_up = views; std::vector<WalkArgs> wargs_up = wargs;
-        if (const char* e = getenv("STITCH_ROT")) { const uint32_t rot = (uint32_t)atoi(e) % nj; std::rotate(views_up.begin(), views_up.begin() + rot, views_up.end()); std::rotate(wargs_up.begin(), wargs_up.begin() + rot, wargs_up.end()); }
-        HIP_TRY(hipMemcpyAsync(d_views, views_up.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(hipMemcpyAsync(d_wargs, wargs_up.data(), sizeof(WalkArgs) * nj, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemcpyAsync(d_views, views.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemcpyAsync(d_wargs, wargs.data(), sizeof(WalkArgs) * nj, hipMemcpyHostToDevice, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
         c.tm.h2d_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h2d0).count();
 
