@@ -83,7 +83,8 @@ struct stitch_ctx {
     uint8_t* d_SnSet0 = nullptr; uint8_t* d_Smove0 = nullptr; uint8_t* d_Imove0 = nullptr; uint32_t* d_lx0 = nullptr;
     JumpBase* d_base0 = nullptr;
     // device arena reused across launches
-    uint8_t* arena = nullptr; size_t arena_bytes = 0;
+    uint8_t* arena = nullptr; size_t arena_bytes = 0;     // arena = arena_raw rounded up to a multiple of 1 GiB
+    uint8_t* arena_raw = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // results of the last batch
     std::vector<stitch_read_result> rr; std::vector<stitch_chain> chains; std::vector<stitch_op> ops;
@@ -188,7 +189,7 @@ int stitch_index_deserialize(const void* buf, size_t len, stitch_index** out) {
 void stitch_ctx_destroy(stitch_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_xseq, c->d_S0, c->d_Slen0, c->d_Sn0, c->d_SnSet0, c->d_Smove0, c->d_Imove0, c->d_lx0, c->d_base0, c->arena, c->pre_buf};
+    void* ptrs[] = {c->d_xseq, c->d_S0, c->d_Slen0, c->d_Sn0, c->d_SnSet0, c->d_Smove0, c->d_Imove0, c->d_lx0, c->d_base0, c->arena_raw, c->pre_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_h2d) (void)hipHostFree(c->pin_h2d);
@@ -428,7 +429,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     size_t arena_need = std::min(want + (1 << 20), budget);
     if (arena_need > c.arena_bytes) {
         if (c.arena) {
-            HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0;
+            HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c.arena_raw)); c.arena_raw = nullptr; c.arena = nullptr; c.arena_bytes = 0;
             // ask again now that the old arena is gone: what the runtime reported as free while it was held need not add up
             HIP_TRY(hipMemGetInfo(&free_b, &total_b));
             size_t b2 = (size_t)(free_b * 0.90);
@@ -437,14 +438,18 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         // a smaller arena only means more launches: shrink until the allocation succeeds or one read no longer fits
         for (;;) {
-            if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] arena -> %zu bytes (%zu jobs, %zu free)\n", arena_need, jobs.size(), free_b);
-            if (hipMalloc((void**)&c.arena, arena_need) == hipSuccess) break;
-            (void)hipGetLastError(); c.arena = nullptr;
+            if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] arena -> %zu bytes (%zu jobs, %zu free), previous base %p\n", arena_need, jobs.size(), free_b, (void*)c.arena_raw);
+            // (the base too is a multiple of the block alignment: the blocks' addresses, not only their distances, are then the
+            // same in every process)
+            const size_t slack = block_align > 256 ? block_align : 0;
+            if (hipMalloc((void**)&c.arena_raw, arena_need + slack) == hipSuccess) { c.arena = (uint8_t*)align_up((size_t)(uintptr_t)c.arena_raw, std::max<size_t>(block_align, 256)); break; }
+            (void)hipGetLastError(); c.arena_raw = nullptr; c.arena = nullptr;
             const size_t smaller = std::max(max_job + ((size_t)1 << 20), (size_t)(arena_need * 0.85));
             if (smaller >= arena_need) return fail(STITCH_ENOMEM, "cannot allocate " + std::to_string(arena_need >> 20) + " MiB of device memory for one read");
             arena_need = smaller;
         }
         c.arena_bytes = arena_need;
+        if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] arena at %p (allocation at %p)\n", (void*)c.arena, (void*)c.arena_raw);
     }
     FillShared sh{c.d_S0, c.d_Slen0, c.d_Sn0, c.d_SnSet0, c.d_Smove0, c.d_lx0, c.d_base0};
     bool fast = true;
