@@ -405,6 +405,10 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         if (a > max_job && a > 256) continue;
         if (const char* e = getenv("STITCH_JOB_ALIGN")) { a = std::max<size_t>(256, (size_t)strtoull(e, nullptr, 10)); }      // (experiments)
         for (size_t k = 0; k < jobs.size(); ++k) lay[k].stride = align_up(lay[k].bytes, a);
+        // a spacing that is a multiple of 4 a leaves the two address bits above the alignment equal in all jobs: measured as bad
+        // as no alignment at all (cfg2 at 4 GiB: 616 ms against 445 at 3 GiB); half the alignment then gives an odd multiple
+        // (14 kb reads: 3.5 GiB spacing 613-688 ms, 4 GiB 845-866)
+        if (a > 256 && !getenv("STITCH_JOB_ALIGN") && align_up(max_job, a) % (4 * a) == 0) continue;
         block_align = a; want = 0;
         // (the Local-mode kernel gives a read of T tiles min(4, ceil(T / 250)) workgroups, see the launch loop below)
         bool all_fast = true; uint32_t gd_min = 4;
