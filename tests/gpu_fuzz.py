@@ -1,5 +1,5 @@
 """GPU fuzz of the Local kernel's multi-tile paths (and the pre-alignment filter) against the oracle.  Not collected by pytest:
-run `FUZZ_SECONDS=600 FUZZ_SEED=1000 python tests/gpu_fuzz.py` on a GPU box (round 1: 8122 cases, all equal; FUZZ_MODES=1 also draws the non-local modes)."""
+run `FUZZ_SECONDS=600 FUZZ_SEED=1000 python tests/gpu_fuzz.py` on a GPU box (round 1: 9971 cases, all equal; FUZZ_MODES=1 also draws the non-local modes)."""
 import os, random, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import stitch_amd
