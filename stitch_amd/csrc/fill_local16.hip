@@ -79,6 +79,9 @@ struct GPtrs {                // hot pointers, kept in registers
 // state vectors and the traceback word at 4 rows per lane), hence vmcnt(3).  Extra (conditional) operations only make the
 // wait stricter.  Rule that goes with it: every hand-issued load must be followed by a tile_wait on the same registers on
 // every path, also the one after the last slot — the compiler tracks neither the loads nor the registers they land in.
+// And the issue must be unconditional: under a branch (tried: skipping the reload after a wave's last slot) the outputs
+// meet the old values in a phi, the compiler copies them right behind the asm, i.e. before the data has landed, and the
+// next tile computes on garbage (the hand-off then never comes: caught by the bounded spins, and by the parity tests).
 #ifndef STITCH_R
 #define STITCH_R 4
 #endif
