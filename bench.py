@@ -50,7 +50,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on one device, gloo instead of RCCL
+        if os.environ.get("STITCH_BENCH_DEVICE") is not None:
+            local_rank = int(os.environ["STITCH_BENCH_DEVICE"])
+        backend = os.environ.get("STITCH_BENCH_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -40,3 +40,22 @@ def test_bench_line_has_the_contract_fields():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "reads/s" and cb["sample"]
     assert cb["gpu_scores_equal_on_sample"] is True
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """the N > 1 path of bench.py (index broadcast, rank shards, barrier, max-over-ranks time, summed counters) with two
+    ranks sharing the one GPU of the test box over gloo (STITCH_BENCH_DEVICE / STITCH_BENCH_BACKEND: rehearsal knobs; the
+    driver's runs use one GPU per rank over RCCL)"""
+    env = dict(os.environ, STITCH_BENCH_DEVICE="0", STITCH_BENCH_BACKEND="gloo", STITCH_ARENA_BYTES=str(8 << 30))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--reads-per-step", "5", "--read-len", "600", "--contigs", "4", "--contig-len", "800"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                   # rank 0 only
+    out = json.loads(lines[0])
+    assert (out["n_gpus"], out["steps"], out["warmup"], out["scaling"]) == (2, 2, 1, "weak")
+    assert abs(out["value"] - 2 * 5 * 1000.0 / out["ms_per_step"]) < 1e-6 * out["value"]     # whole-job rate over both ranks
+    assert "cpu_baseline" not in out                                # N = 1 only
