@@ -432,13 +432,12 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] job blocks at multiples of %zu bytes, window %zu bytes\n", block_align, want);
     size_t arena_need = std::min(want + (1 << 20), budget);
     if (arena_need > c.arena_bytes) {
+        // growing costs seconds (free + allocate: ~5 s for 250 GB), so a context that has to grow takes half as much again
+        if (c.arena) arena_need = std::min(budget, arena_need + arena_need / 2);
         if (c.arena) {
             HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c.arena_raw)); c.arena_raw = nullptr; c.arena = nullptr; c.arena_bytes = 0;
-            // ask again now that the old arena is gone: what the runtime reported as free while it was held need not add up
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            size_t b2 = (size_t)(free_b * 0.90);
-            if (c.mem_limit) b2 = std::min(b2, c.mem_limit);
-            arena_need = std::min(arena_need, std::max(b2, max_job + ((size_t)1 << 20)));
+            // (what hipMemGetInfo reports right after the free lags behind, in both directions on different runs: the request
+            // stays what the budget above allows, and the loop below shrinks it if the allocation fails)
         }
         // a smaller arena only means more launches: shrink until the allocation succeeds or one read no longer fits
         for (;;) {
