@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64) void banded_score_kernel(const BandPair* __rest
 // fetched together and broadcast from registers.  Rows are tied to lanes by row mod 64, so a column is processed in
 // 64-aligned blocks of rows and the insertion chain is a DPP prefix maximum in 32 bits (keys T - ge*i >= 0, "none" = -1;
 // the host checks that they fit).  One wavefront per pair, no barriers: a wavefront's LDS operations execute in order.
-constexpr uint32_t BAND_RING = 1024;
+constexpr uint32_t BAND_RING = 512;
 constexpr size_t BAND_LDS_MAX = 64 << 10;
 __device__ __forceinline__ int32_t dpp_max_shr(int32_t v, int32_t none) {            // inclusive prefix maximum over the 64 lanes
 #define STITCH_DPP_STEP(CTRL, ROWMASK) { const int32_t o = __builtin_amdgcn_update_dpp(none, v, CTRL, ROWMASK, 0xF, false); v = o > v ? o : v; }

@@ -191,7 +191,7 @@ def test_banded_kernel_wide_bands_and_long_targets():
 def test_banded_kernels_agree_ring_tall_and_global(monkeypatch):
     """the LDS-ring kernel, the global-state kernel it replaces (STITCH_BANDED_GLOBAL) and the oracle give the same scores:
     w = 20 gives columns of one or two 64-row blocks, w = 200 of several, and w = 300 makes columns taller than the ring
-    (1201 > 1024 rows for the first read), which must take the global-state kernel"""
+    (1201 > 512 rows for the first read), which must take the global-state kernel"""
     import stitch_amd
     rng = random.Random(17)
     t0, t1 = rnd(rng, 2600), rnd(rng, 900)
