@@ -5,16 +5,22 @@ ONT reads vs a 50 x 5 kb construct DB; configs[1]).
   python bench.py --gpus N --steps K --warmup W [--reads-per-step R]
 
 A step = one pass of the hot path (stitch_align_batch: DP fill, per-column jump reduce, fix-ups, traceback, chain
-assembly) over one batch of R synthetic reads per GPU.  Reads are sharded by rank (weak scaling: R per GPU is
-fixed); the only collective on the data path is the one-time broadcast of the serialized reference index from
-rank 0 (RCCL), outside the timed region.  Rank 0 prints ONE JSON line.
+assembly) over one batch of R synthetic reads per GPU.  ONE synthetic read stream is generated (the same on every
+rank) and each step's N*R reads are sharded by rank at read-group boundaries (stitch_amd.dist.shard_range == the
+reference's FastxGroupingIterator rule), weak scaling: R per GPU is fixed.  The only collective on the data path is the
+one-time broadcast of the serialized reference index from rank 0 (RCCL), outside the timed region.  Rank 0 prints ONE
+JSON line.
 
-roofline: the dominant kernel is the DP fill (stitch::fill_kernel).  `achieved` = algorithmic bytes (1 byte of
-traceback per DP cell) / the kernel's launch time measured inside the library with HIP events on
-the stream it runs on (stitch_last_timing).  cpu_baseline: the oracle (C++ restatement of the reference, "port")
-timed on this host on a bounded sample of the same workload, rank 0 at N=1 only.
+roofline: the dominant kernel is the DP fill.  `achieved` = algorithmic bytes (1 byte of traceback per DP cell,
+SURVEY.md 8d) / the kernel's launch time measured inside the library with HIP events on the stream it runs on
+(stitch_last_timing).  `traffic` and the wave-time split come from the committed rocprofv3 --pmc passes of the SAME
+kernel sources (profiles/collect.sh records a hash of them; when it differs from the sources in this tree the figures are
+left out as stale).  cpu_baseline: the oracle (C++ restatement of the reference, "port") timed on this host with the
+reference's worker model on a bounded sample of the same workload, rank 0 at N=1 only, SAM text diffed against the HIP path.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -26,6 +32,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SHADER_CLOCK_HZ = 2.4e9    # MI355X_MICROARCH.md "Chip-level parameters": max clock 2400 MHz
+# MI355X_MICROARCH.md "Wave scheduling": 4 SIMD-32 per CU, a wave64 VALU instruction issues over 2 cycles
+VALU_CYCLES_PER_WAVE_INST = 2.0
+FILL_KERNELS = {0: "stitch::fill_kernel", 1: "stitch::fill_local16_kernel", 2: "stitch::fill_regs_kernel"}      # stitch_timing.fill_kind
+KERNEL_SOURCES = ("fill_local16.hip", "fill_regs.hip", "dp_core.h", "walk_core.h", "stitch_api.cpp")
+
+
+def kernel_src_hash():
+    """Hash of the sources that decide what the fill kernel does and how it is launched (profiles/collect.sh stores it)."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        p = os.path.join(ROOT, "stitch_amd", "csrc", f)
+        if os.path.exists(p):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def host_memory_available():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
 
 
 def main():
@@ -37,9 +68,9 @@ def main():
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--contigs", type=int, default=50)
     ap.add_argument("--contig-len", type=int, default=5000)
-    ap.add_argument("--cpu-reads", type=int, default=1, help="reads in the cpu_baseline sample (0 = skip)")
-    ap.add_argument("--cpu-prefix", type=int, default=1000, help="bases of each sample read the CPU aligns (0 = whole read: ~40 GB, minutes)")
-    ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--cpu-reads", type=int, default=-1, help="reads in the cpu_baseline sample (-1 = one per worker thread, 0 = skip)")
+    ap.add_argument("--cpu-prefix", type=int, default=2500, help="bases of each sample read the CPU aligns (0 = whole read: 40 GB and minutes per read)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="worker threads of the CPU leg (0 = min(cores, free RAM / RAM per worker, 16))")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,16 +103,19 @@ def main():
         index = sdist.broadcast_index(index, dist, dev, src=0)          # the one collective: RCCL broadcast of the index blob
     aligners = stitch_amd.Aligners(stitch_amd.Builder().build_options(), index, device=local_rank)
 
-    # ---- this rank's shard of the synthetic reads (seed 42 + config id 2; rank-specific stream) ----------------
+    # ---- ONE synthetic read stream (seed 42 + config id 2), every step's world * R reads sharded by rank -------
     R = args.reads_per_step
     total_steps = args.warmup + args.steps
-    reads = synth.make_reads(db, R * total_steps, args.read_len, 44 + 1000 * rank)
-    batches = []
+    stream = synth.make_reads(db, R * world * total_steps, args.read_len, 44)
+    batches, my_reads = [], []
     for s in range(total_steps):
-        chunk = reads[s * R:(s + 1) * R]
+        step_reads = stream[s * R * world:(s + 1) * R * world]
+        lo, hi = sdist.shard_range(step_reads, world, rank)
+        chunk = step_reads[lo:hi]
         offs = np.zeros(len(chunk) + 1, dtype=np.uint64)
         offs[1:] = np.cumsum([len(r) for r in chunk])
         batches.append((np.frombuffer(b"".join(chunk), dtype=np.uint8), offs))
+        my_reads.append(len(chunk))
 
     def sync():
         torch.cuda.synchronize()
@@ -97,26 +131,32 @@ def main():
     cells = 0
     launches = 0
     mapped = 0
+    n_mine = 0
+    kernel_name = None
     for s in range(args.warmup, total_steps):
         rr, ch, _ops = aligners.align_packed_raw(*batches[s])       # result arena views: what a compiled front end would read
         tm = aligners.timing()
         fill_ms += tm["fill_ms"]; walk_ms += tm["walk_ms"]; cells += tm["cells"]; launches += tm["launches"]
-        mapped += int((ch["score"][rr["chains_begin"][rr["n_chains"] > 0]] >= 100).sum())
+        kernel_name = FILL_KERNELS.get(tm.get("fill_kind", 1), kernel_name)
+        n_mine += my_reads[s]
+        if len(ch):
+            mapped += int((ch["score"][rr["chains_begin"][rr["n_chains"] > 0]] >= 100).sum())
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        agg = torch.tensor([float(cells), fill_ms, float(launches)], dtype=torch.float64, device=dev)
+        agg = torch.tensor([float(cells), float(n_mine)], dtype=torch.float64, device=dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        cells_all = float(agg[0].item())
+        cells_all, n_reads_all = float(agg[0].item()), int(round(float(agg[1].item())))
     else:
-        cells_all = float(cells)
+        cells_all, n_reads_all = float(cells), n_mine
 
     if rank == 0:
-        n_reads_all = R * args.steps * world
         value = n_reads_all / dt
+        kernel_name = kernel_name or "stitch::fill_local16_kernel"
+        prop = torch.cuda.get_device_properties(local_rank)
         # roofline of the dominant kernel (this rank's launches; every rank runs the same kernel on the same shape)
         fill_s = fill_ms / 1e3
         achieved = (cells * 1.0 / fill_s) / 1e9 if fill_s > 0 else 0.0           # GB/s at 1 algorithmic byte per cell
@@ -127,56 +167,90 @@ def main():
             "config": {"workload": f"{args.read_len} bp chimeric ONT-like reads vs {args.contigs}x{args.contig_len} bp construct DB, "
                                    "local mode, single strand (BASELINE configs[1])",
                        "reads_per_step_per_gpu": R, "cells_per_read": args.read_len * args.contigs * args.contig_len,
-                       "scoring": "A=1 B=-4 O=-6 E=-2 J=-10", "sharding": "reads by rank, index broadcast once"},
+                       "scoring": "A=1 B=-4 O=-6 E=-2 J=-10", "sharding": "one read stream cut by rank at read-group boundaries, index broadcast once"},
             "gcells_per_sec": cells_all / dt / 1e9,
-            "device": (lambda p: {"name": p.name, "cus": p.multi_processor_count, "hbm_gib": round(p.total_memory / 2**30)})(torch.cuda.get_device_properties(local_rank)),
-            "mapped_fraction": mapped / float(R * args.steps),
-            "roofline": {"bound": "hbm", "kernel": "stitch::fill_local16_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "device": {"name": prop.name, "cus": prop.multi_processor_count, "hbm_gib": round(prop.total_memory / 2**30)},
+            "mapped_fraction": mapped / float(max(1, n_mine)),
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_cell": 1.0, "cells_per_launch": cells / max(1, launches),
                          "avg_launch_ms": fill_ms / max(1, launches), "walk_kernel_ms_per_step": walk_ms / args.steps,
                          "fill_gcells_per_sec": cells / fill_s / 1e9 if fill_s > 0 else 0.0},
         }
-        # HBM-side traffic of the fill kernel: PMC counters cannot be read from inside this process, so the figure is
-        # the committed rocprofv3 --pmc measurement (profiles/, separate FETCH_SIZE and WRITE_SIZE passes of this same
-        # command, KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) scaled per cell.
+        # HBM-side traffic and the wave-time split of the fill kernel: PMC counters cannot be read from inside this process, so
+        # the figures are the committed rocprofv3 --pmc measurement (profiles/, separate FETCH_SIZE and WRITE_SIZE passes of this
+        # same command, KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled per cell — and only
+        # when that measurement was taken on the kernel sources of this tree.
         try:
-            import glob
-            pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_local16.json")))[-1]        # the latest committed pass
-            pmc = json.load(open(pmc_path))
-            k = pmc["stitch::fill_local16_kernel"]
-            bpc = (2.0 * k["FETCH_SIZE"]["avg_per_launch_raw"] + k["WRITE_SIZE"]["avg_per_launch_raw"]) * 1024.0 / pmc["cells_per_launch"]
-            out["roofline"]["traffic"] = bpc * cells / max(1, launches)
-            # second view, as SURVEY.md 8(d) asks: integer VALU issue.  A wave64 integer instruction occupies its SIMD for 4 clocks
-            # (16 lanes/clock), so the ceiling is 256 CU x 4 SIMD x 2.4 GHz / 4 wave-instructions/s.
-            vpc = k["SQ_INSTS_VALU"]["avg_per_launch_raw"] * 64.0 / pmc["cells_per_launch"]
-            out["roofline"]["valu"] = {"wave_insts_per_64_cells": vpc, "achieved_wave_insts_per_s": vpc * (cells / 64.0) / fill_s,
-                                       "peak_wave_insts_per_s": 256 * 4 * 2.4e9 / 4, "frac": vpc * (cells / 64.0) / fill_s / (256 * 4 * 2.4e9 / 4)}
-            out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(pmc_path)}: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch of "
-                                                 f"{pmc['cells_per_launch']:.3g} cells = {bpc:.2f} B/cell, scaled to this run's cells per launch")
-        except (OSError, KeyError, ValueError, IndexError, TypeError):
+            src = kernel_src_hash()
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")))
+            pmc_path, pmc = None, None
+            for p in reversed(cands):
+                d = json.load(open(p))
+                if d.get("kernel_src_sha") == src and kernel_name in d:
+                    pmc_path, pmc = p, d
+                    break
+            if pmc is None:
+                out["roofline"]["traffic_source"] = (f"no committed PMC pass matches the kernel sources of this tree (hash {src}): "
+                                                     "traffic and the wave-time split are left out rather than reported stale")
+            else:
+                k = pmc[kernel_name]
+                cpl = pmc["cells_per_launch"]
+                bpc = (2.0 * k["FETCH_SIZE"]["avg_per_launch_raw"] + k["WRITE_SIZE"]["avg_per_launch_raw"]) * 1024.0 / cpl
+                out["roofline"]["traffic"] = bpc * cells / max(1, launches)
+                out["roofline"]["traffic_bytes_per_cell"] = bpc
+                # second view, as SURVEY.md 8(d) asks: integer VALU issue against 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction
+                vpc = k["SQ_INSTS_VALU"]["avg_per_launch_raw"] * 64.0 / cpl
+                peak = prop.multi_processor_count * 4 * SHADER_CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST
+                out["roofline"]["valu"] = {"wave_insts_per_64_cells": vpc, "achieved_wave_insts_per_s": vpc * (cells / 64.0) / fill_s,
+                                           "peak_wave_insts_per_s": peak, "frac": vpc * (cells / 64.0) / fill_s / peak,
+                                           "peak_source": "MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction issues over 2 cycles"}
+                if "SQ_WAVE_CYCLES" in k and "SQ_WAIT_ANY" in k:
+                    wc = k["SQ_WAVE_CYCLES"]["avg_per_launch_raw"]
+                    out["roofline"]["wave_time_split"] = {n_: k[c_]["avg_per_launch_raw"] / wc for n_, c_ in
+                                                          (("wait_any", "SQ_WAIT_ANY"), ("wait_inst_any", "SQ_WAIT_INST_ANY"), ("active_inst_any", "SQ_ACTIVE_INST_ANY")) if c_ in k}
+                out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(pmc_path)} (kernel sources {src}): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch of "
+                                                     f"{cpl:.3g} cells = {bpc:.2f} B/cell, scaled to this run's cells per launch")
+        except (OSError, KeyError, ValueError, IndexError, TypeError, ZeroDivisionError):
             pass
-        if world == 1 and args.cpu_reads > 0:
-            from oracle import oracle as orc
-            # One 10 kb read is 2.5e9 cells and 40 GB of 16-byte traceback cells for the reference layout (minutes per read
-            # per core), so the bounded sample is a PREFIX of the first read(s) against the full DB; reads/s is scaled by
-            # cells (the DP cost is linear in read length).
-            pre = args.cpu_prefix if args.cpu_prefix > 0 else args.read_len
-            sample = [r[:pre] for r in reads[:args.cpu_reads]]
-            secs, ccells, cscores = orc.cpu_bench([(n, s) for n, s in db], sample, threads=args.cpu_threads)
-            # the same sample through the HIP path: the two sides must agree (parity proper is tests/, this is a run-time cross-check)
-            gres = aligners.align(sample)
-            same = all(len(g[0]) > 0 and g[0][0].score == int(cscores[k]) for k, g in enumerate(gres))
-            cells_per_read = args.read_len * args.contigs * args.contig_len
-            out["cpu_baseline"] = {"value": ccells / secs / cells_per_read, "unit": "reads/s", "cores": args.cpu_threads, "kind": "port",
-                                   "gcells_per_sec": ccells / secs / 1e9, "gpu_scores_equal_on_sample": bool(same),
-                                   "sample": f"first {pre} bp of the first {len(sample)} read(s) vs the full DB: {ccells} cells in {secs:.1f} s on "
-                                             f"{args.cpu_threads} thread(s); reads/s = cells/s / {cells_per_read} cells per {args.read_len} bp read; C++ "
-                                             f"restatement of fulcrumgenomics/stitch with its 16-byte row-major traceback cells "
-                                             f"({os.cpu_count()} host cores visible)"}
+        if world == 1 and args.cpu_reads != 0:
+            out["cpu_baseline"] = cpu_leg(args, db, stream, aligners)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def cpu_leg(args, db, stream, aligners):
+    """the C++ restatement of the reference with the reference's worker model — T threads, one aligner set
+    (16-byte row-major traceback matrices of every contig) per thread, chunks of 10 records — on a bounded sample of the
+    same read stream; SAM text from both sides diffed on that sample."""
+    from oracle import oracle as orc
+    pre = args.cpu_prefix if 0 < args.cpu_prefix < args.read_len else args.read_len
+    rows = args.contigs * (args.contig_len + 1)
+    ram_per_worker = rows * (pre + 1) * 16                      # traceback/mod.rs:122-126
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    free = host_memory_available()
+    T = args.cpu_threads if args.cpu_threads > 0 else max(1, min(cores, int(free * 0.6 // max(1, ram_per_worker)), 16))
+    n_sample = args.cpu_reads if args.cpu_reads > 0 else T
+    # distinct reads (a duplicated neighbour is the same job for both sides), each cut to the stated prefix
+    sample = []
+    for r in stream:
+        if not sample or r != stream[len(sample) - 1]:
+            sample.append(r[:pre])
+        if len(sample) == n_sample:
+            break
+    secs, ccells, _scores, csam = orc.cpu_bench_sam([(n, s) for n, s in db], sample, threads=T, name_base=0)
+    # the same sample through the HIP path: SAM text must be identical (parity proper is tests/, this is the run-time diff)
+    aligners.align(sample)
+    gsam = ["".join(l + "\n" for l in aligners.format_sam(k, f"read_{k:07d}", sample[k], b"I" * len(sample[k]))) for k in range(len(sample))]
+    same = [g == c for g, c in zip(gsam, csam)]
+    cells_per_read = args.read_len * args.contigs * args.contig_len
+    return {"value": ccells / secs / cells_per_read, "unit": "reads/s", "cores": T, "kind": "port",
+            "gcells_per_sec": ccells / secs / 1e9, "sam_identical_on_sample": bool(all(same)), "sam_reads_compared": len(same),
+            "sample": f"first {pre} bp of the first {len(sample)} distinct read(s) vs the full DB: {ccells} cells in {secs:.1f} s on {T} worker "
+                      f"thread(s) (one aligner set per thread, chunks of 10 records; {cores} cores usable, {free / 2**30:.0f} GiB host RAM "
+                      f"available, {ram_per_worker / 2**30:.1f} GiB of 16-byte traceback cells per worker); reads/s = cells/s / {cells_per_read} "
+                      f"cells per {args.read_len} bp read; C++ restatement of fulcrumgenomics/stitch (g++ -O3, portable flags), not the Rust binary"}
 
 
 if __name__ == "__main__":

@@ -198,21 +198,40 @@ long orc_al_format_sam(void* hh, const char* head, const uint8_t* bases, size_t 
 // CPU baseline leg (bench.py only): align `n_reads` reads with `threads` worker threads, each owning its own
 // Aligners (one aligner set per thread, fg-stitch-cli/src/commands/align.rs:345-390).  Returns wall seconds;
 // cells_out = sum of DP cells filled.
+double orc_bench_sam(const int32_t* opts, const float* fopts, size_t n_targets, const char* const* names,
+                     const uint8_t* const* seqs, const size_t* lens, const uint8_t* reads, const uint64_t* offsets,
+                     size_t n_reads, int threads, uint64_t* cells_out, int64_t* scores_out,
+                     size_t name_base, char* sam_buf, size_t sam_cap, uint64_t* sam_offsets);
 double orc_bench(const int32_t* opts, const float* fopts, size_t n_targets, const char* const* names,
                  const uint8_t* const* seqs, const size_t* lens, const uint8_t* reads, const uint64_t* offsets,
                  size_t n_reads, int threads, uint64_t* cells_out, int64_t* scores_out) {
+    return orc_bench_sam(opts, fopts, n_targets, names, seqs, lens, reads, offsets, n_reads, threads, cells_out, scores_out, 0, nullptr, 0, nullptr);
+}
+// The same with the worker model of fg-stitch-cli/src/commands/align.rs:345-390 spelled out: `threads` workers, each with its
+// own aligner set, pulling chunks of 10 records (align/io.rs:178-245), and the SAM text of every read (records '\n'-joined,
+// header line "read_%07zu" numbered from name_base, qualities all 'I') written to sam_buf at sam_offsets[r]..sam_offsets[r+1]
+// AFTER the clock has stopped (formatting runs on the reference's single writer thread and is not part of the aligners' time).
+double orc_bench_sam(const int32_t* opts, const float* fopts, size_t n_targets, const char* const* names,
+                     const uint8_t* const* seqs, const size_t* lens, const uint8_t* reads, const uint64_t* offsets,
+                     size_t n_reads, int threads, uint64_t* cells_out, int64_t* scores_out,
+                     size_t name_base, char* sam_buf, size_t sam_cap, uint64_t* sam_offsets) {
     std::atomic<size_t> next{0};
     std::atomic<uint64_t> cells{0};
+    std::vector<std::vector<Alignment>> all_chains(n_reads);
+    Options o = get_options(opts, fopts);
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; ++t) {
         pool.emplace_back([&]() {
             auto* h = (OrcAligners*)orc_al_new(opts, fopts, n_targets, names, seqs, lens);
             for (;;) {
-                size_t r = next.fetch_add(1);
-                if (r >= n_reads) break;
-                h->chains = h->al.align(reads + offsets[r], (size_t)(offsets[r + 1] - offsets[r]));
-                if (scores_out) scores_out[r] = h->chains.empty() ? 0 : h->chains[0].score;
+                const size_t r0 = next.fetch_add(10);
+                if (r0 >= n_reads) break;
+                for (size_t r = r0; r < std::min(n_reads, r0 + 10); ++r) {
+                    h->chains = h->al.align(reads + offsets[r], (size_t)(offsets[r + 1] - offsets[r]));
+                    if (scores_out) scores_out[r] = h->chains.empty() ? 0 : h->chains[0].score;
+                    if (sam_buf) all_chains[r] = h->chains;
+                }
             }
             cells += h->al.multi_contig.cells_filled;
             delete h;
@@ -221,6 +240,25 @@ double orc_bench(const int32_t* opts, const float* fopts, size_t n_targets, cons
     for (auto& th : pool) th.join();
     auto t1 = std::chrono::steady_clock::now();
     if (cells_out) *cells_out = cells.load();
+    if (sam_buf && sam_offsets) {
+        auto* h = (OrcAligners*)orc_al_new(opts, fopts, n_targets, names, seqs, lens);
+        size_t at = 0;
+        for (size_t r = 0; r < n_reads; ++r) {
+            sam_offsets[r] = at;
+            const size_t n = (size_t)(offsets[r + 1] - offsets[r]);
+            std::vector<uint8_t> b(reads + offsets[r], reads + offsets[r] + n), q(n, (uint8_t)'I');
+            char head[64]; snprintf(head, sizeof(head), "read_%07zu", name_base + r);
+            std::string err;
+            auto recs = format_sam(o, h->targets, head, b, &q, all_chains[r], std::nullopt, &err);
+            for (size_t k = 0; k < recs.size(); ++k) {
+                const std::string line = recs[k] + "\n";
+                if (at + line.size() <= sam_cap) memcpy(sam_buf + at, line.data(), line.size());
+                at += line.size();
+            }
+        }
+        sam_offsets[n_reads] = at;
+        delete h;
+    }
     return std::chrono::duration<double>(t1 - t0).count();
 }
 

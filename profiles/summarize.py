@@ -10,6 +10,8 @@ from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(here))
+from bench import kernel_src_hash          # the hash bench.py compares before it quotes these counters
 
 stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
@@ -34,6 +36,7 @@ for log in glob.glob(os.path.join(out, "pmc_*.log")):                       # th
             cells = json.loads(line)["roofline"]["cells_per_launch"]
 if summary:
     summary["cells_per_launch"] = cells
+    summary["kernel_src_sha"] = kernel_src_hash()
     summary["units"] = "FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them (FETCH_SIZE counts half of a wide read on gfx950)"
     with open(os.path.join(here, f"{tag}_pmc_local16.json"), "w") as f:
         json.dump(summary, f, indent=1)

@@ -92,7 +92,25 @@ __device__ __forceinline__ void tile_load_plain(TileRegs& r, gptr<const u32x4> p
     r.v0 = p[0]; r.v1 = p[1];
     if constexpr (R == 8) { r.v2 = p[2]; r.v3 = p[3]; r.x = *(gptr<const u32x2>)px; } else { r.x.x = *(gptr<const uint32_t>)px; }
 }
+// Experiment builds (never shipped; results are garbage, only the kernel time is read — DESIGN.md "what bounds the fill"):
+//   -DSTITCH_EXP_NOSTATE  the row state makes no round trip through memory: a tile's results stay in the registers and are
+//                         the next tile's input (no state loads, no state stores)
+//   -DSTITCH_EXP_NOTB     no traceback bytes and no y-suffix records are stored
+#if defined(STITCH_EXP_NOSTATE) && defined(STITCH_EXP_NOTB)
+#define EXP_VMCNT "0"
+#elif defined(STITCH_EXP_NOSTATE)
+#define EXP_VMCNT "1"
+#elif defined(STITCH_EXP_NOTB)
+#define EXP_VMCNT "2"
+#else
+#define EXP_VMCNT "3"
+#endif
 __device__ __forceinline__ void tile_load(TileRegs& r, gptr<const u32x4> p, gptr<const uint8_t> px) {
+#ifdef STITCH_EXP_NOSTATE
+    static_assert(R == 4, "experiment builds are R == 4");
+    asm volatile("global_load_dword %0, %1, off" : "=&v"(r.x.x) : "v"(px) : "memory");
+    return;
+#endif
     if constexpr (R == 8) {
         asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
                      "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
@@ -107,7 +125,7 @@ __device__ __forceinline__ void tile_load(TileRegs& r, gptr<const u32x4> p, gptr
 // wait until only the stores of the tile computed in between may still be in flight: R/2 state vectors + 1 traceback store
 __device__ __forceinline__ void tile_wait(TileRegs& r) {
     if constexpr (R == 8) asm volatile("s_waitcnt vmcnt(5)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.v2), "+v"(r.v3), "+v"(r.x) : : "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.x.x) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(" EXP_VMCNT ")" : "+v"(r.v0), "+v"(r.v1), "+v"(r.x.x) : : "memory");
 }
 __device__ __forceinline__ void tile_wait_all(TileRegs& r) {
     if constexpr (R == 8) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.v2), "+v"(r.v3), "+v"(r.x) : : "memory");
@@ -337,6 +355,7 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
     // checks the invariant), so the reference's test `S > Sn || (S == Sn && len > 0)` is `len > 0`, i.e. the S word > 0, and
     // the record {S word, n - j} is stored without reading Sn back.  With a chimeric read every cell is reached by a jump
     // from the best column maximum, so this happens in a quarter of all rows: one masked 8-byte store per row.
+#ifndef STITCH_EXP_NOTB
     if ((int32_t)(tk >> 16) >= wc.vrun) {
         const gptr<u32x2> yr = V.yrec + r;
 #pragma unroll
@@ -344,9 +363,19 @@ __device__ __forceinline__ void tile(const GPtrs& V, const WordConsts& K, const 
             if ((!PARTIAL || i0 + u < m) && Fo[u] >= wc.thr) { u32x2 rec; rec.x = (uint32_t)Fo[u]; rec.y = wc.n - wc.j; yr[u] = rec; }
         }
     }
+#endif
+#ifdef STITCH_EXP_NOSTATE
+    tr.v0.x = (uint32_t)Fo[0]; tr.v0.y = (uint32_t)ra[0].BD; tr.v0.z = (uint32_t)Fo[1]; tr.v0.w = (uint32_t)ra[1].BD;
+    tr.v1.x = (uint32_t)Fo[2]; tr.v1.y = (uint32_t)ra[2].BD; tr.v1.z = (uint32_t)Fo[3]; tr.v1.w = (uint32_t)ra[3].BD;
+#else
     gptr<u32x4> stw = (gptr<u32x4>)(V.st + 2 * (size_t)r);
 #pragma unroll
     for (int v = 0; v < R / 2; ++v) { u32x4 o; o.x = (uint32_t)Fo[2 * v]; o.y = (uint32_t)ra[2 * v].BD; o.z = (uint32_t)Fo[2 * v + 1]; o.w = (uint32_t)ra[2 * v + 1].BD; stw[v] = o; }
+#endif
+#ifdef STITCH_EXP_NOTB
+    (void)tbcol; (void)code;
+    return;
+#endif
     if constexpr (R == 8) {
         u32x2 tbv;
         tbv.x = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);

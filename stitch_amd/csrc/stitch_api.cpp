@@ -69,8 +69,27 @@ struct Job {                                     // one full jump DP
     std::vector<uint32_t> status;
 };
 
+// Diagnostic / experiment knobs, read from the environment ONCE when a context is created (never per launch).
+struct Knobs {
+    bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false;
+    size_t array_align = 0, job_align = 0;
+    int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0;
+    static Knobs from_env() {
+        Knobs k;
+        auto num = [](const char* name) -> unsigned long long { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : 0ull; };
+        k.debug = getenv("STITCH_DEBUG") != nullptr; k.force_generic = getenv("STITCH_FORCE_GENERIC") != nullptr;
+        k.profile_dump = getenv("STITCH_PROFILE_DUMP") != nullptr; k.banded_global = getenv("STITCH_BANDED_GLOBAL") != nullptr;
+        k.fill_only = getenv("STITCH_EXP_FILL_ONLY") != nullptr;      // experiment builds whose results are garbage: time the fill, skip the walk
+        k.no_regs = getenv("STITCH_NO_REGS") != nullptr;             // keep the state-streaming kernel even where the register-resident one applies
+        k.array_align = (size_t)num("STITCH_ARRAY_ALIGN"); k.job_align = (size_t)num("STITCH_JOB_ALIGN");
+        k.max_waves = (int)num("STITCH_MAX_WAVES"); k.wg_per_read = (int)num("STITCH_WG_PER_READ"); k.tiles_per_wave = (int)num("STITCH_TILES_PER_WAVE");
+        return k;
+    }
+};
+
 struct stitch_ctx {
     int device = 0;
+    Knobs knobs;
     stitch_opts opts{};
     DpParams P{};
     std::vector<TargetInfo> targets;
@@ -288,6 +307,7 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
         HIP_TRY(hipMalloc((void**)&c->pre_buf, c->pre_bytes));
     }
     if (const char* lim = getenv("STITCH_ARENA_BYTES")) c->mem_limit = (size_t)strtoull(lim, nullptr, 10);
+    c->knobs = Knobs::from_env();
     *out = c.release();
     return STITCH_OK;
 }
@@ -319,8 +339,7 @@ JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
     // the arrays the fill kernel streams every column (row state, y-suffix records, traceback) start at multiples of 2 MiB in
     // jobs that are large enough not to notice (measured on cfg2: 3-4 % over 256-byte packing; 4 KiB: nothing, 64 MiB: the same)
-    static const size_t big_env = [] { const char* e = getenv("STITCH_ARRAY_ALIGN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0; }();   // (experiments)
-    const size_t big_align = big_env ? big_env : (8ull * R >= ((size_t)1 << 20) ? (size_t)2 << 20 : (size_t)256);
+    const size_t big_align = c.knobs.array_align ? c.knobs.array_align : (8ull * R >= ((size_t)1 << 20) ? (size_t)2 << 20 : (size_t)256);
     auto take_big = [&](size_t bytes) { if (big_align > 256) o = align_up(o, big_align); return take(bytes); };
     L.off_S = take(4ull * R); L.off_Slen = take(4ull * R); L.off_D = take_big(4ull * R); L.off_Dlen = take(4ull * R);
     if (L.off_Dlen != L.off_D + 4ull * R) abort();      // fill_local16.hip keeps its 8-byte y-suffix records in D..Dlen
@@ -341,7 +360,7 @@ JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
 // The Local-mode kernel keeps scores and alignment lengths in 16 bits (fill_local16.hip).
 bool local16_ok(const stitch_ctx& c, const Job& jb) {
     const stitch_opts& o = c.opts;
-    if (getenv("STITCH_FORCE_GENERIC")) return false;
+    if (c.knobs.force_generic) return false;
     const long long n = (long long)jb.y.size();
     const int32_t lo = std::min({o.mismatch_score, o.gap_open + o.gap_extend, o.jump_same, o.jump_opposite, o.jump_inter, o.match_score});
     uint32_t tiles = 0; for (uint32_t a : jb.act) tiles += (c.al[a].m + 255) / 256;      // 256-row tiles when built with 4 rows per lane
@@ -356,8 +375,8 @@ constexpr int MAX_WAVES_GENERIC = 8;               // fill_kernel.hip: __launch_
 #endif
 constexpr int MAX_WAVES_LOCAL = STITCH_LB / 64;       // fill_local16.hip: __launch_bounds__(STITCH_LB), 12 waves
 
-int pick_waves(uint32_t nact, int maxw) {          // fewest rounds of contigs per column, then fewest waves
-    if (const char* e = getenv("STITCH_MAX_WAVES")) maxw = std::max(1, std::min(maxw, atoi(e)));
+int pick_waves(const stitch_ctx& c, uint32_t nact, int maxw) {          // fewest rounds of contigs per column, then fewest waves
+    if (c.knobs.max_waves) maxw = std::max(1, std::min(maxw, c.knobs.max_waves));
     int best_w = 1, best_rounds = (int)nact;
     for (int w = 1; w <= maxw; ++w) { int r = ((int)nact + w - 1) / w; if (r < best_rounds) { best_rounds = r; best_w = w; } }
     return best_w;
@@ -403,12 +422,12 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     size_t want = 0, block_align = 256;
     for (size_t a = (size_t)1 << 30; a >= 256; a >>= 1) {
         if (a > max_job && a > 256) continue;
-        if (const char* e = getenv("STITCH_JOB_ALIGN")) { a = std::max<size_t>(256, (size_t)strtoull(e, nullptr, 10)); }      // (experiments)
+        if (c.knobs.job_align) a = std::max<size_t>(256, c.knobs.job_align);      // (experiments)
         for (size_t k = 0; k < jobs.size(); ++k) lay[k].stride = align_up(lay[k].bytes, a);
         // a spacing that is a multiple of 4 a leaves the two address bits above the alignment equal in all jobs: measured as bad
         // as no alignment at all (cfg2 at 4 GiB: 616 ms against 445 at 3 GiB); half the alignment then gives an odd multiple
         // (14 kb reads: 3.5 GiB spacing 613-688 ms, 4 GiB 845-866)
-        if (a > 256 && !getenv("STITCH_JOB_ALIGN") && align_up(max_job, a) % (4 * a) == 0) continue;
+        if (a > 256 && !c.knobs.job_align && align_up(max_job, a) % (4 * a) == 0) continue;
         block_align = a; want = 0;
         // (the Local-mode kernel gives a read of T tiles min(4, ceil(T / 250)) workgroups, see the launch loop below)
         bool all_fast = true; uint32_t gd_min = 4;
@@ -418,7 +437,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             gd_min = std::min(gd_min, std::min(4u, std::max(1u, (tiles + 249u) / 250u)));
         }
         // (reads that get ONE workgroup each do not wait for anybody, so any number of them shares a launch)
-        if (const char* g = getenv("STITCH_WG_PER_READ")) gd_min = (uint32_t)std::max(1, atoi(g));          // (experiments)
+        if (c.knobs.wg_per_read) gd_min = (uint32_t)c.knobs.wg_per_read;          // (experiments)
         const size_t win = (all_fast && gd_min > 1) ? std::min<size_t>(jobs.size(), (size_t)std::max(1, c.n_cus) / gd_min) : jobs.size();
         size_t cur = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
@@ -427,9 +446,9 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             want = std::max(want, cur);
         }
         want += (size_t)2 << 20;
-        if (want + (1 << 20) <= budget || a == 256 || getenv("STITCH_JOB_ALIGN")) break;      // fits (or nothing smaller to try)
+        if (want + (1 << 20) <= budget || a == 256 || c.knobs.job_align) break;      // fits (or nothing smaller to try)
     }
-    if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] job blocks at multiples of %zu bytes, window %zu bytes\n", block_align, want);
+    if (c.knobs.debug) fprintf(stderr, "[stitch] job blocks at multiples of %zu bytes, window %zu bytes\n", block_align, want);
     size_t arena_need = std::min(want + (1 << 20), budget);
     if (arena_need > c.arena_bytes) {
         // growing costs seconds (free + allocate: ~5 s for 250 GB), so a context that has to grow takes half as much again
@@ -441,7 +460,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         // a smaller arena only means more launches: shrink until the allocation succeeds or one read no longer fits
         for (;;) {
-            if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] arena -> %zu bytes (%zu jobs, %zu free), previous base %p\n", arena_need, jobs.size(), free_b, (void*)c.arena_raw);
+            if (c.knobs.debug) fprintf(stderr, "[stitch] arena -> %zu bytes (%zu jobs, %zu free), previous base %p\n", arena_need, jobs.size(), free_b, (void*)c.arena_raw);
             // (the base too is a multiple of the block alignment: the blocks' addresses, not only their distances, are then the
             // same in every process)
             const size_t slack = block_align > 256 ? block_align : 0;
@@ -452,7 +471,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             arena_need = smaller;
         }
         c.arena_bytes = arena_need;
-        if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] arena at %p (allocation at %p)\n", (void*)c.arena, (void*)c.arena_raw);
+        if (c.knobs.debug) fprintf(stderr, "[stitch] arena at %p (allocation at %p)\n", (void*)c.arena, (void*)c.arena_raw);
     }
     FillShared sh{c.d_S0, c.d_Slen0, c.d_Sn0, c.d_SnSet0, c.d_Smove0, c.d_lx0, c.d_base0};
     bool fast = true;
@@ -480,7 +499,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             // one workgroup per read: nothing waits across workgroups, so the launch may hold more reads than there are CUs
             // (two or three such workgroups of a few waves share a CU and fill each other's per-column stalls)
             if (std::max(g_min, g_des) == 1) max_jobs = 4096;
-            if (const char* g = getenv("STITCH_WG_PER_READ")) max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, (uint32_t)std::max(1, atoi(g))));
+            if (c.knobs.wg_per_read) max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, (uint32_t)c.knobs.wg_per_read));
         }
         const size_t per_job = sizeof(JobView) + sizeof(WalkArgs) + 512;     // the launch's job table, after the jobs' own buffers
         while (k1 < jobs.size() && used + lay[k1].stride + per_job + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].stride + per_job; ++k1; }
@@ -504,7 +523,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         for (uint32_t q = 0; q < nj; ++q) {
             const Job& jb = jobs[k0 + q]; const JobLayout& L = lay[k0 + q];
             base[q] = o; uint8_t* B = c.arena + o; o += L.stride;
-            waves = std::max(waves, pick_waves(L.nact, MAX_WAVES_GENERIC));
+            waves = std::max(waves, pick_waves(c, L.nact, MAX_WAVES_GENERIC));
             // per-job tables
             std::vector<ContigDesc> cd(c.C); std::vector<int32_t> opp(c.C, -1); std::vector<uint8_t> isact(c.C, 0);
             for (uint32_t a : jb.act) isact[a] = 1;
@@ -568,7 +587,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
                 const double eff = (double)min_act / g / (double)((min_act + g - 1) / g);
                 if (g * eff > best + 1e-9) { best = g * eff; G = g; }
             }
-            if (const char* g = getenv("STITCH_WG_PER_READ")) G = std::max(1u, (uint32_t)atoi(g));
+            if (c.knobs.wg_per_read) G = (uint32_t)c.knobs.wg_per_read;
             G = std::max(G, g_min);
             if (nj * G > cus) G = std::max(1u, cus / nj);
             // the waves of a workgroup share its tiles evenly (fill_local16.hip), so use all 12 unless there are fewer tiles
@@ -576,11 +595,11 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             for (uint32_t q = 0; q < nj; ++q) { uint32_t t = 0; for (uint32_t a : jobs[k0 + q].act) t += (c.al[a].m + 255) / 256; min_tiles = std::min(min_tiles, t / G); }
             // ... of a few tiles each: a contig cut across waves is a serial chain of hand-offs within a column (about 1 us
             // each), which dominates when a workgroup holds only a contig or two (re-alignment jobs on a chain's contigs)
-            uint32_t tpw = 5; if (const char* e = getenv("STITCH_TILES_PER_WAVE")) tpw = (uint32_t)std::max(1, atoi(e));
+            const uint32_t tpw = c.knobs.tiles_per_wave ? (uint32_t)c.knobs.tiles_per_wave : 5u;
             waves = (int)std::max(1u, std::min<uint32_t>(MAX_WAVES_LOCAL, min_tiles / tpw));
-            if (const char* e = getenv("STITCH_MAX_WAVES")) waves = std::max(1, std::min(waves, atoi(e)));
+            if (c.knobs.max_waves) waves = std::max(1, std::min(waves, c.knobs.max_waves));
         }
-        c.tm_wg_per_read = G;
+        c.tm_wg_per_read = G; c.tm.wg_per_read = G; c.tm.fill_kind = fast ? 1u : 0u;
         uint32_t slots_cap = 0;                          // tiles of the launch's largest workgroup (contigs are dealt round-robin to a read's G workgroups)
         if (fast) for (uint32_t q = 0; q < nj; ++q) {
             std::vector<uint32_t> per(G, 0);
@@ -592,7 +611,13 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         else launch_fill(d_views, nj, waves, sh, c.stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev[1], c.stream));
-        if (getenv("STITCH_DEBUG")) { HIP_TRY(hipStreamSynchronize(c.stream)); fprintf(stderr, "[stitch] fill done (%u jobs, fast=%d)\n", nj, (int)fast); }
+        if (c.knobs.debug) { HIP_TRY(hipStreamSynchronize(c.stream)); fprintf(stderr, "[stitch] fill done (%u jobs, fast=%d)\n", nj, (int)fast); }
+        if (c.knobs.fill_only) {        // experiment builds (garbage results): the fill's time is all that is wanted
+            HIP_TRY(hipStreamSynchronize(c.stream));
+            float ms_f = 0; HIP_TRY(hipEventElapsedTime(&ms_f, c.ev[0], c.ev[1])); c.tm.fill_ms += ms_f; c.tm.launches += 1; c.tm.jobs += nj;
+            if (c.knobs.debug) fprintf(stderr, "[stitch] fill-only launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms\n", nj, G, waves, ms_f);
+            k0 = k1; continue;
+        }
         uint32_t max_nact_mode1 = 0;
         for (uint32_t q = 0; q < nj; ++q) if (jobs[k0 + q].mode == 1) max_nact_mode1 = std::max(max_nact_mode1, lay[k0 + q].nact);
         launch_fixup_walk(d_views, d_wargs, nj, max_nact_mode1, c.stream);
@@ -603,9 +628,9 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         float ms_fill = 0;
         HIP_TRY(hipEventElapsedTime(&ms_fill, c.ev[0], c.ev[1])); c.tm.fill_ms += ms_fill;
         HIP_TRY(hipEventElapsedTime(&ms, c.ev[1], c.ev[2])); c.tm.walk_ms += ms;
-        if (getenv("STITCH_DEBUG")) fprintf(stderr, "[stitch] launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms, fix-up + walk %.1f ms\n", nj, G, waves, ms_fill, ms);
+        if (c.knobs.debug) fprintf(stderr, "[stitch] launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms, fix-up + walk %.1f ms\n", nj, G, waves, ms_fill, ms);
         c.tm.launches += 1; c.tm.jobs += nj;
-        if (getenv("STITCH_PROFILE_DUMP") && fast) {
+        if (c.knobs.profile_dump && fast) {
             unsigned long long pf[128]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[0].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
             unsigned long long t_first = ~0ull;
             std::vector<unsigned long long> t_end(nj);
@@ -825,7 +850,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         // kernel (arithmetic-bound): both read the uploads above and write disjoint scores
         HIP_TRY(hipEventRecord(c.ev2[0], c.stream));
         HIP_TRY(hipStreamWaitEvent(c.stream2, c.ev2[0], 0));
-        if (getenv("STITCH_BANDED_GLOBAL") || !launch_banded_scores_lds(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream2))
+        if (c.knobs.banded_global || !launch_banded_scores_lds(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream2))
             launch_banded_scores(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream2);
         launch_banded_scores(d_pairs, d_tall, (uint32_t)S.tall_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream2);
         HIP_TRY(hipEventRecord(c.ev2[1], c.stream2));
@@ -1007,12 +1032,18 @@ int stitch_align_batch(stitch_ctx* c, const uint8_t* bases, const uint64_t* offs
         for (size_t k = 0; k < jobs.size(); ++k) if (pre_has[k]) { live_of.push_back(k); live.push_back(std::move(jobs[k])); }
         jobs.swap(live);
     } else { live_of.resize(jobs.size()); for (size_t k = 0; k < jobs.size(); ++k) live_of[k] = k; }
-    const bool dbg = getenv("STITCH_DEBUG") != nullptr;
+    const bool dbg = c->knobs.debug;
     auto stamp = [&](const char* what) { if (dbg) fprintf(stderr, "[stitch] %-28s at %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count()); };
     stamp("jobs built / pre-aligned");
     rc = run_jobs(*c, jobs);
     if (rc) return rc;
     stamp("pass 1 done");
+    if (c->knobs.fill_only) {           // experiment: no chains exist
+        c->rr.assign(n_reads, stitch_read_result{});
+        if (per_read) *per_read = c->rr.data(); if (chains) *chains = c->chains.data(); if (ops) *ops = c->ops.data();
+        if (cells_filled) *cells_filled = c->tm.cells;
+        return STITCH_OK;
+    }
 
     // host: chains of pass 1, realign planning
     struct PerJob { std::vector<HAln> chains; std::vector<RealignPlan> plans; };

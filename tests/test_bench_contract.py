@@ -25,7 +25,7 @@ def test_bench_refuses_to_run_without_a_gpu():
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
     r = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--reads-per-step", "6", "--read-len", "500", "--contigs", "4",
-                  "--contig-len", "700", "--cpu-reads", "1", "--cpu-prefix", "200")
+                  "--contig-len", "700", "--cpu-reads", "3", "--cpu-prefix", "200", "--cpu-threads", "2")
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -36,10 +36,10 @@ def test_bench_line_has_the_contract_fields():
     assert "workload" in out["config"] and "model" not in out["config"]
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["achieved"] > 0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel"] == "stitch::fill_local16_kernel"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel"] in ("stitch::fill_local16_kernel", "stitch::fill_regs_kernel")
     cb = out["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "reads/s" and cb["sample"]
-    assert cb["gpu_scores_equal_on_sample"] is True
+    assert cb["kind"] == "port" and cb["cores"] == 2 and cb["value"] > 0 and cb["unit"] == "reads/s" and cb["sample"]
+    assert cb["sam_identical_on_sample"] is True and cb["sam_reads_compared"] == 3
 
 
 @pytest.mark.gpu

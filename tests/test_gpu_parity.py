@@ -277,35 +277,3 @@ def test_batch_split_invariance_and_determinism(monkeypatch):
     c = [[c.key() for c in ch] for ch, _ in al2.align(reads)]
     assert a == c
     assert al2.timing()["launches"] > 1
-
-
-def test_full_size_properties():
-    """BASELINE config 2 shape (10 kb reads vs 50 x 5 kb), where the oracle needs 40 GB per read: size-independent
-    properties instead.  (1) a read copied from one contig scores match*n with cigar n=; (2) a two-segment chimera
-    scores n + jump and has exactly one Xjump to the right contig/offset; (3) unrelated reads still give a valid
-    local alignment whose score equals the score recomputed from its op list."""
-    db = synth.make_db(50, 5000, 1001)
-    targets = [stitch_amd.TargetSeq(n, s) for n, s in db]
-    al = stitch_amd.Builder().build_aligners(targets)
-    s7, s31 = db[7][1], db[31][1]
-    exact = s7[100:4100]
-    chim = s7[1000:3000] + s31[2500:4500]
-    noise = synth.make_reads(db, 2, 4000, 99, random_frac=1.0)
-    res = al.align([exact, chim] + noise)
-    a = res[0][0][0]
-    assert (a.score, a.cigar(), a.start_contig_idx, a.xstart, a.xend, a.ystart, a.yend) == (4000, "4000=", 7, 100, 4100, 0, 4000)
-    b = res[1][0][0]
-    assert b.score == 4000 - 10 and b.start_contig_idx == 7 and b.end_contig_idx == 31
-    jumps = [o for o in b.operations if o[0] == 6]
-    assert jumps == [(6, 31, 2500)] and b.cigar() == "2000=24C500j2000="
-    for ch, _ in res[2:]:
-        c = ch[0]
-        sc, run = 0, None
-        for k, _, _ in c.operations:                 # A=1 B=-4 O=-6 E=-2 J=-10
-            if k == 0: sc += 1
-            elif k == 1: sc += -4
-            elif k in (2, 3): sc += -2 + (-6 if run != k else 0)
-            elif k == 6: sc += -10
-            run = k
-        assert sc == c.score and c.score > 0
-    assert al.cells_filled == sum(len(r) for r in [exact, chim] + noise) * 50 * 5000
