@@ -1,0 +1,493 @@
+// Kernel 1c — the Local-mode DP fill with the row state RESIDENT IN REGISTERS, one contig per wavefront.
+//
+// Same recurrence, tie-breaks and outputs as fill_local16.hip (fg-stitch-lib/src/align/aligners/single_contig_aligner.rs:188-451
+// + multi_contig_aligner.rs:264-347; dp_core.h holds the word arithmetic both kernels execute).  What differs:
+//   * ROWS -> LANES.  A wave owns one contig of up to 64 x RMAX rows; lane l holds a run of CONSECUTIVE rows, a multiple of four
+//     (S word and D word of every row in two VGPRs: 2 x RMAX = 160 of the wave's 256 registers) for the whole read.  The row
+//     state never touches memory; per column a wave writes its traceback bytes and y-suffix records and nothing else
+//     (fill_local16 streams 16 B of state per cell through L2 and the fabric).
+//   * One insertion scan per CONTIG and column instead of one per 256-row tile: the chain I[i] = max(I[i-1]+ge, S'[i-1]+go+ge)
+//     runs serially down a lane's rows (a compare and two selects per row) and crosses lanes once, as a lane-tagged DPP prefix
+//     maximum.  The per-tile overheads of the tiled kernels (scan, reductions, slot bookkeeping) go.
+//   * Registers 4g+3 .. 4g of a lane = four consecutive rows ("group" g), top to bottom; a lane's rows end at register 0, so the
+//     value the NEXT lane needs is always in register 0.  The contig's ceil(m / 4) groups are dealt to the lanes as evenly as
+//     possible (the first lanes hold one group more); the unrolled code of a group runs under `g < groups of this lane`.
+//   * A read's contigs are dealt to the waves of G workgroups (a team); per column the team exchanges the per-contig column
+//     arg-max (the next column's jump sources, get_jump_info :677-697) through one 8-byte granule {column, score, len, from} per
+//     contig and column parity, written by the wave that owns the contig and polled by every wave on its own: there is no
+//     workgroup barrier in the column loop, and the polled records stay in registers.
+//   * y-suffix records (:431-447) are kept for cells that reach the best score seen so far in ANY contig (mode traceback) or in
+//     their own contig (traceback_all / traceback_from): DESIGN.md "y-suffix records".
+// Eligibility (stitch_api.cpp regs_plan): what fill_local16 admits, and: not circular, every contig <= 64 x RMAX rows,
+// |ge| x 64 x RMAX small enough for lane-tagged scan keys.  Everything else runs fill_local16 / the generic kernel.
+// Traceback bytes and y-suffix records are stored lane-interleaved (walk_core.h tb_row_offset, V.tb_keyfmt == 2) so that every
+// store instruction writes whole 256-byte lines.  All spins are bounded and end the kernel with an error word, never a hang.
+#include <type_traits>
+#include <hip/hip_runtime.h>
+#include "dp_core.h"
+#include "walk_core.h"
+#include "fill_common.h"
+
+namespace stitch {
+namespace {
+
+constexpr int RMAX = REGS_RMAX;                // rows per lane (walk_core.h: the traceback layout depends on it)
+constexpr int NG = RMAX / 4;                   // groups of four rows: one traceback dword, one word of bases
+static_assert(RMAX == 80, "the group blocks below are written out for 20 groups");
+constexpr uint32_t RSRC_WORD3 = 0x00020000u;   // raw buffer descriptor, gfx94x / gfx950
+constexpr int AUX_NT = 2;                      // streamed once: non-temporal
+
+// per wave in LDS: NG x 64 words of bases (constant), NG x 64 words of traceback codes (pass 1 -> pass 2), RMAX x 64 scores of
+// best{diagonal, deletion} (pass 1 -> the insertion merge of pass 2)
+constexpr uint32_t LDS_XW = 0, LDS_TB = NG * 64 * 4, LDS_BS = 2 * NG * 64 * 4, LDS_PER_WAVE = 2 * NG * 64 * 4 + RMAX * 64 * 2;
+
+// wave-uniform values of one contig's column, and the lane's rolling values of the row loop of pass 1
+struct Col {
+    int32_t MW1, XW1, GE1, GO1, JSWm1;         // (match, mismatch) << 16 | 1; gap words; the column's jump word minus one length unit
+    uint32_t q;                                // y[j-1]
+    int32_t ge;
+    int32_t kbase, qbase;                      // per lane: scan key / length terms of register 0 (register IDX adds ge * IDX / IDX)
+    int32_t aw1, DG;                           // the current row's (match | mismatch) word and diagonal candidate: old S word of the row above + aw1
+    uint32_t xw;                               // four bases: the group of the NEXT row
+    int32_t Tup;                               // new S' word of the row above (insertion scan)
+    ScanEl inc;                                // the lane's running scan element (earliest opener wins ties)
+    int32_t dgm; uint32_t pad;                 // row m (register `pad` of its lane): its diagonal candidate, needed for its finalisation
+};
+
+// ---- pass 1, one row (register IDX): everything of the cell that needs column j-1 only (dp_core.h row_phase_a_word), written
+// in place; the row's scan element joins the lane's running one; the score of best{diagonal, deletion} is parked in LDS for
+// the insertion merge of pass 2
+template <int IDX>
+__device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32_t& tbw, Col& c, const uint32_t* xw_lane, uint16_t* bs_lane) {
+    constexpr int k = IDX & 3;
+    const int32_t aw1 = c.aw1, DG = c.DG;                    // prepared by the row above (or the column's prologue)
+    const int32_t Sold = (int32_t)Sreg, Dold = (int32_t)Dreg;
+    if (IDX > 0) {
+        // the NEXT row's diagonal candidate takes this row's old S word: computed here, so that the old word is dead before the
+        // new one is written and the row's S register is updated in place
+        if (k == 0) c.xw = xw_lane[((IDX > 0 ? IDX - 1 : 0) >> 2) * 64];
+        const uint32_t xbn = (c.xw >> (8 * (k == 0 ? 3 : k - 1))) & 0xFFu;
+        c.aw1 = xbn == c.q ? c.MW1 : c.XW1;
+        c.DG = Sold + c.aw1;                                 // diagonal: score + a, length + 1
+    }
+    const int32_t DE = Dold + c.GE1, DO = Sold + c.GO1;
+    const bool dext = (DE | 0xFFFF) >= DO;                   // the extension wins ties (:332)
+    const int32_t BD = dext ? DE : DO;
+    const int32_t DGh = DG | 0xFFFF, BDh = BD | 0xFFFF;
+    const bool c1 = BD > DGh;                                // deletion strictly better than the diagonal
+    const int32_t bs2 = c1 ? BD : DG;
+    const int32_t X = c1 ? BDh : DG;                         // what the jump has to beat (:373-382)
+    const int32_t JW = aw1 + c.JSWm1;
+    const bool c3 = JW > X;
+    int32_t T = c3 ? JW : bs2;
+    const bool c4 = T < 0;                                   // x-prefix clip: score 0, length 0
+    T = c4 ? 0 : T;
+    const uint32_t code = (c4 ? MK_XPRE : c3 ? MK_JUMP : c1 ? MK_DEL : MK_DIAG) | (dext ? (uint32_t)TBB_DEXT : 0u);
+    tbw = k == 3 ? code : ((tbw << 8) | code);               // byte k of the group's dword: register 4g+3 first, 4g last
+    bs_lane[IDX * 64] = (uint16_t)((uint32_t)bs2 >> 16);
+    if (IDX < 4) { if (c.pad == (uint32_t)IDX) c.dgm = DG; }
+    // insertion scan element of this row: opened from the row above (key_i = S'(i-1) + go + ge - ge * i, q_i = S'.len(i-1) + 1 - i,
+    // i = the row's 1-based index in the contig)
+    ScanEl el; el.key = word_score(c.Tup) + (c.kbase + c.ge * IDX); el.q = (int32_t)word_len(c.Tup) + (c.qbase + IDX);
+    c.inc = scan_combine(c.inc, el);
+    c.Tup = T;
+    Sreg = (uint32_t)T; Dreg = (uint32_t)BD;
+}
+
+struct Col2 {
+    int32_t MW, XW, JSW, ge; uint32_t q;
+    int32_t kbase, qbase, bbase, lbase;        // per lane: key / length terms as in pass 1; I score = run.key + bbase - ge * IDX, I length = run.q + lbase - IDX
+    uint32_t xw; int32_t Tup;
+    ScanEl run;                                // the chain's value before the current row
+    uint32_t lastcol; uint32_t rg4;            // j == n; 4 x (index of register 0's row in the job's linear row arrays)
+    __amdgpu_buffer_rsrc_t rS; uint32_t oSlen, oIval, oIlen;          // the last column's int32 arrays: one descriptor, byte offsets from V.S
+};
+
+// ---- pass 2, one row: the chain's "extended" bit, and the merge of the insertion into the cell where it changes it
+// (dp_core.h row_phase_c_word: beats best{diagonal, deletion}, is not beaten by the jump)
+template <int IDX>
+__device__ __forceinline__ void row_pass2(uint32_t& Sreg, uint32_t& tbw, Col2& c, const uint16_t* bs_lane, const bool real) {
+    constexpr int k = IDX & 3;
+    ScanEl el; el.key = word_score(c.Tup) + (c.kbase + c.ge * IDX); el.q = (int32_t)word_len(c.Tup) + (c.qbase + IDX);
+    const bool ext = c.run.key >= el.key;
+    if (!ext) c.run = el;
+    const int32_t bi = c.run.key + (c.bbase - c.ge * IDX);
+    const int32_t T = (int32_t)Sreg;
+    uint32_t byte = (tbw >> (8 * k)) & 0xFFu;
+    byte |= ext ? (uint32_t)TBB_IEXT : 0u;
+    const int32_t bih = (int32_t)(((uint32_t)bi << 16) | 0xFFFFu);
+    // the insertion can only change the cell if its score reaches the cell's (T >= 0, so a negative insertion never does)
+    int32_t Tn = T;
+    if (__ballot(bi >= 0 && bih >= T) != 0ull) {
+        const uint32_t il = (uint32_t)(c.run.q + (c.lbase - IDX));
+        const uint32_t xb = (c.xw >> (8 * k)) & 0xFFu;
+        RowW ra;
+        ra.T = T; ra.mvT = byte & 7u;
+        ra.JW = c.JSW + (xb == c.q ? c.MW : c.XW);
+        ra.bs2h = (int32_t)(((uint32_t)bs_lane[IDX * 64] << 16) | 0xFFFFu);
+        uint32_t mv;
+        Tn = row_phase_c_word(ra, bi, il, mv);
+        byte = (byte & ~7u) | mv;
+    }
+    if (c.lastcol != 0u) {
+        // column n: the int32 arrays the fix-up kernel reads (single_contig_aligner.rs:453-555)
+        if (real) {
+            const uint32_t il = (uint32_t)(c.run.q + (c.lbase - IDX));
+            const uint32_t vo = c.rg4 - 4u * IDX;
+            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score(Tn), c.rS, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len(Tn), c.rS, vo, c.oSlen, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)bi, c.rS, vo, c.oIval, 0); __builtin_amdgcn_raw_buffer_store_b32(il, c.rS, vo, c.oIlen, 0);
+        }
+    }
+    tbw = (tbw & ~(0xFFu << (8 * k))) | (byte << (8 * k));
+    Sreg = (uint32_t)Tn;
+    c.Tup = T;                                  // the scan runs on S WITHOUT its own insertion candidate (dp_core.h, phase B)
+}
+
+// the lane's running records over a contig's column (rows below m): the largest S word and the topmost row holding it (x-suffix
+// running max :406-429); the topmost row holding the largest score, and its length (column arg-max :677-697)
+struct Recs { uint32_t bw, xrow, r1, len1; };
+
+__device__ __forceinline__ void group_records(Recs& R, const uint32_t t3, const uint32_t t2, const uint32_t t1, const uint32_t t0, const uint32_t row3) {
+    uint32_t g4 = t3 > t2 ? t3 : t2; g4 = t1 > g4 ? t1 : g4; g4 = t0 > g4 ? t0 : g4;
+    if (g4 > R.bw) {
+        const uint32_t kk = t3 == g4 ? 0u : t2 == g4 ? 1u : t1 == g4 ? 2u : 3u;            // rows down from the group's top row
+        R.xrow = row3 + kk;
+        if ((g4 >> 16) > (R.bw >> 16) || R.r1 == 0xFFFFFFFFu) {
+            const uint32_t s4 = g4 >> 16;
+            const uint32_t k1 = (t3 >> 16) == s4 ? 0u : (t2 >> 16) == s4 ? 1u : (t1 >> 16) == s4 ? 2u : 3u;
+            R.r1 = row3 + k1;
+            R.len1 = (k1 == 0u ? t3 : k1 == 1u ? t2 : k1 == 2u ? t1 : t0) & 0xFFFFu;
+        }
+        R.bw = g4;
+    }
+}
+
+#define REP20(X) X(19) X(18) X(17) X(16) X(15) X(14) X(13) X(12) X(11) X(10) X(9) X(8) X(7) X(6) X(5) X(4) X(3) X(2) X(1) X(0)
+
+}  // namespace
+
+// NQ = granule registers per lane: 1 for up to 64 active contigs, 4 for up to 256
+template <int NQ>
+__global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restrict__ jobs, FillShared sh, uint32_t G) {
+    // (the quotient comes out of vector arithmetic: tell the compiler it is uniform, so that everything read through V is scalar)
+    const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / G));
+    const JobView& V = jobs[job];
+    const uint32_t part = blockIdx.x - job * G;
+    const DpParams P = V.P;
+    const uint32_t n = V.n, nact = V.nact, Rtot = V.Rtot, C = V.C;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform, provably)
+    const uint32_t RW = blockDim.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    uint8_t* const s_wave = s_dyn + (size_t)wave * LDS_PER_WAVE;
+
+    // ---- this wave's contig: active contig number (part * RW + wave) ------------------------------------------------------------
+    const uint32_t kmine = part * RW + (uint32_t)wave;
+    if (kmine >= nact) return;                        // (more waves than contigs: nobody waits for this wave)
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)V.act[kmine]);
+    ContigDesc cd = V.cd[c];
+    cd.m = (uint32_t)__builtin_amdgcn_readfirstlane((int)cd.m); cd.roff = (uint32_t)__builtin_amdgcn_readfirstlane((int)cd.roff);
+    cd.troff = (uint32_t)__builtin_amdgcn_readfirstlane((int)cd.troff); cd.seqoff = (uint32_t)__builtin_amdgcn_readfirstlane((int)cd.seqoff);
+    const uint32_t m = cd.m, roff = cd.roff;
+    // position of the same-name opposite strand in the active list (-1: none in this subset)
+    int32_t kopp = -1;
+    { const int32_t opp = V.opp_act[c]; if (opp >= 0) for (uint32_t k = 0; k < nact; ++k) if ((int32_t)V.act[k] == opp) kopp = (int32_t)k; }
+    kopp = __builtin_amdgcn_readfirstlane(kopp);
+    // groups of four rows -> lanes
+    const uint32_t ngr = (m + 3) / 4, gq = ngr / 64, grem = ngr % 64;
+    const uint32_t gl = gq + ((uint32_t)lane < grem ? 1u : 0u);                     // groups of this lane
+    const uint32_t nrows = 4 * gl;
+    const uint32_t rowbase = 4 * ((uint32_t)lane * gq + ((uint32_t)lane < grem ? (uint32_t)lane : grem));   // 0-based row of the lane's first row
+    const uint32_t pad = 4 * ngr - m;                 // 0..3 registers without a row, at the bottom of the last lane that has rows
+    const int mlane = (int)(gq > 0 ? 63u : grem - 1u);            // row m: register `pad` of that lane
+    const uint32_t gtop = gq + (grem > 0 ? 1u : 0u);  // groups of the fullest lane: the unrolled blocks g >= gtop are skipped by every lane
+    const int32_t jump_same = P.jump_same, jump_opp = P.jump_opp, jump_inter = P.jump_inter;
+    const int32_t MW = (int32_t)((uint32_t)P.match << 16), XW = (int32_t)((uint32_t)P.mismatch << 16);
+    const int32_t GE1 = (int32_t)((uint32_t)P.gap_extend << 16) + 1, GO1 = (int32_t)((uint32_t)(P.gap_open + P.gap_extend) << 16) + 1;
+    const int32_t ge = P.gap_extend, kb0 = P.gap_open + P.gap_extend;
+    const gptr<const uint8_t> yseq = as_global(V.y);
+    const gptr<u32x2> yrec = (gptr<u32x2>)as_global(V.D);      // [Rtot] 8-byte records: D and Dlen are contiguous (layout_job)
+    const gptr<unsigned long long> xchg = as_global(V.xchg);
+    const bool ymode_global = V.yrec_global != 0;
+    // register IDX of this lane holds the contig's row (1-based) pos1 = rowbase + nrows - IDX
+    const int32_t pos1_0 = (int32_t)(rowbase + nrows);                  // ... of register 0
+    // scan terms of register IDX: key = S'.score + kbase + ge * IDX, q = S'.len + qbase + IDX with kbase = go + ge - ge * pos1_0, qbase = 1 - pos1_0;
+    // I score = run.key + bbase - ge * IDX, I length = run.q + lbase - IDX with bbase = ge * pos1_0, lbase = pos1_0
+
+    // ---- column 0 (init_matrices :97-186): registers, bases, per-row arrays of this wave's rows -----------------------------------
+    uint32_t S[RMAX], D[RMAX];
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) { S[i] = 0u; D[i] = (uint32_t)word_make(-16384, 0); }     // D = "MIN": never extends, never wins, cannot wrap
+    {
+        uint32_t* const xw0 = (uint32_t*)(s_wave + LDS_XW) + lane;
+#define INIT(g) if ((uint32_t)(g) < gl) { \
+            uint32_t w = 0; \
+            _Pragma("unroll") for (int k = 3; k >= 0; --k) { \
+                const uint32_t row = rowbase + (nrows - 1 - (4u * (g) + (uint32_t)k));                    /* 0-based row of the contig */ \
+                uint32_t b = 0xFFu;                                                                         /* no row: equals no base */ \
+                if (row < m) { \
+                    const uint32_t tr = cd.troff + row; \
+                    S[4 * (g) + k] = (uint32_t)word_make(sh.S0[tr], sh.Slen0[tr]); \
+                    u32x2 rec; rec.x = (uint32_t)word_make(sh.Sn0[tr], sh.Slen0[tr]); rec.y = sh.SnSet0[tr] ? n : 0u; \
+                    yrec[roff + (4u * (g) + (uint32_t)k) * 64u + (uint32_t)lane] = rec; \
+                    V.SmoveF[roff + row] = TB_NONE; V.ImoveF[roff + row] = TB_NONE; \
+                    b = V.xseq[cd.seqoff + row]; \
+                } \
+                w |= b << (8 * k); \
+            } \
+            xw0[(g) * 64] = w; \
+        }
+        REP20(INIT)
+#undef INIT
+    }
+    if (lane == 0) V.Lx[(size_t)c * (n + 1)] = sh.lx0[c];
+    int32_t vrun = sh.base0[c].score;                                     // the contig's running maximum over columns < j
+    int32_t gmax = 0;                                                     // best score of any contig in columns < j (row 0 holds 0)
+    // the contigs' column arg-max of column j-1, lane l holding active contigs l, l + 64, ...: {column, score, len, from} granules
+    unsigned long long gv[NQ];
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) gv[qq] = 0ull;
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+        const uint32_t k = (uint32_t)lane + 64u * qq;
+        if (k < nact) { const JumpBase b = sh.base0[V.act[k]]; gv[qq] = ((unsigned long long)(uint32_t)(b.score & 0xFFFF) << 32) | ((unsigned long long)(b.len & 0xFFFFu) << 16) | (b.from & 0xFFFFu); gmax = b.score > gmax ? b.score : gmax; }
+    }
+    gmax = (int32_t)wave_max_u32((uint32_t)gmax);
+
+    uint32_t ychunk = 0;
+    for (uint32_t j = 1; j <= n; ++j) {
+        const bool lastcol = j == n;
+        // ---- poll the team's granules of column j-1 (column 0 came from the host) --------------------------------------------------
+        if (j > 1) {
+            const uint32_t want = j - 1;
+            const gptr<unsigned long long> gb = xchg + (size_t)(want & 1u) * C;
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int qq = 0; qq < NQ; ++qq) {
+                    const uint32_t k = (uint32_t)lane + 64u * qq;
+                    if (k < nact) { gv[qq] = __hip_atomic_load(gb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok &= (uint32_t)(gv[qq] >> 48) == want; }
+                }
+                if (__all(ok)) break;
+                if (wall_clock64() - t0 > 400000000ull) { if (lane == 0) *V.err = 1; return; }      // 4 s at 100 MHz: a partner is not resident
+                __builtin_amdgcn_s_sleep(1);
+            }
+            uint32_t best = 0;
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq) { const uint32_t sc = (uint32_t)(gv[qq] >> 32) & 0xFFFFu; best = ((uint32_t)lane + 64u * qq < nact && sc > best) ? sc : best; }
+            const int32_t colmax = (int32_t)wave_max_u32(best);
+            gmax = colmax > gmax ? colmax : gmax;
+        }
+        // the read's bases, 64 columns per (coalesced) load: lane l holds y[jb + l]
+        if (((j - 1) & 63u) == 0) ychunk = (j - 1 + lane < n) ? (uint32_t)yseq[j - 1 + lane] : 0u;
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)ychunk, (int)((j - 1) & 63u)) & 0xFFu;
+
+        // ---- best jump out of column j-1 for this contig (multi_contig_aligner.rs:292-331): inter-contig = max by (score, len),
+        // LAST aligner on full ties (max_by_key); the records of active contig k sit in lane k % 64, register k / 64
+        auto rec_of = [&](uint32_t k) -> unsigned long long {
+            const uint32_t w = k >> 6;
+            unsigned long long v = gv[0];
+#pragma unroll
+            for (int qq = 1; qq < NQ; ++qq) v = w == (uint32_t)qq ? gv[qq] : v;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)(k & 63u)), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)(k & 63u));
+            return ((unsigned long long)hi << 32) | lo;
+        };
+        JumpInfo ji;
+        {
+            unsigned long long ik = 0;
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq) {
+                const uint32_t k = (uint32_t)lane + 64u * qq;
+                if (k < nact && k != kmine && (int32_t)k != kopp) {
+                    const unsigned long long key = ((gv[qq] & 0x0000FFFFFFFF0000ull) << 0) | (k + 1);      // score << 32 | len << 16 | k + 1
+                    ik = key > ik ? key : ik;
+                }
+            }
+            ik = wave_max_u64(ik);
+            { const unsigned long long b = rec_of(kmine); ji.score = (int32_t)((b >> 32) & 0xFFFFu) + jump_same; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = c; ji.from = (uint32_t)b & 0xFFFFu; }
+            if (kopp >= 0) { const unsigned long long b = rec_of((uint32_t)kopp); const int32_t sc = (int32_t)((b >> 32) & 0xFFFFu) + jump_opp; if (sc > ji.score) { ji.score = sc; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = V.act[kopp]; ji.from = (uint32_t)b & 0xFFFFu; } }
+            if (ik != 0) {
+                const uint32_t kw = (uint32_t)(ik & 0xFFFFu) - 1; const unsigned long long b = rec_of(kw);
+                const int32_t sc = (int32_t)((b >> 32) & 0xFFFFu) + jump_inter;
+                if (sc > ji.score) { ji.score = sc; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = V.act[kw]; ji.from = (uint32_t)b & 0xFFFFu; }
+            }
+            if (lane == 0) { V.jt_idx[(size_t)c * (n + 1) + j] = ji.idx; V.jt_from[(size_t)c * (n + 1) + j] = ji.from; }
+        }
+        const int32_t JSW = __builtin_amdgcn_readfirstlane(word_make(ji.score, ji.len));
+        // y-suffix records are kept for cells whose score reaches ybase (never for a zero word)
+        const int32_t ybase = ymode_global ? gmax : vrun;
+        const int32_t ythr = ybase > 0 ? (int32_t)((uint32_t)ybase << 16) : 1;
+
+        // (what depends only on the lane is constant over the read: the compiler would hoist the base words and the group guards out
+        // of the column loop and pin registers for them; values it cannot see through keep them one LDS read / one compare each)
+        int lane_x = lane; uint32_t gl_x = gl; int32_t pos_x = pos1_0; asm volatile("" : "+v"(lane_x), "+v"(gl_x), "+v"(pos_x));
+        const int32_t kbase = kb0 - ge * pos_x, qbase = 1 - pos_x, bbase = ge * pos_x, lbase = pos_x;
+        const int32_t kfirst = kbase + ge * (4 * (int32_t)gl_x - 1), qfirst = qbase + 4 * (int32_t)gl_x - 1;       // the same for the lane's first row
+        const uint32_t rg4_x = 4u * (roff + (uint32_t)pos_x - 1u);       // 4 x (linear row index of register 0's row)
+        const uint32_t* const xw_lane = (const uint32_t*)(s_wave + LDS_XW) + lane_x;
+        uint32_t* const tb_lane = (uint32_t*)(s_wave + LDS_TB) + lane_x;
+        uint16_t* const bs_lane = (uint16_t*)(s_wave + LDS_BS) + lane_x;
+
+        // ---- pass 1: rows top to bottom = registers 4 gl - 1 .. 0 ------------------------------------------------------------------
+        Col cx;
+        cx.MW1 = MW + 1; cx.XW1 = XW + 1; cx.GE1 = GE1; cx.GO1 = GO1; cx.JSWm1 = JSW - 1; cx.q = q; cx.ge = ge; cx.kbase = kbase; cx.qbase = qbase;
+        cx.Tup = 0;                                                       // (placeholder for the lane's first row: see below)
+        cx.inc.key = SCAN_LOW; cx.inc.q = 0;
+        cx.dgm = 0; cx.pad = pad;
+        cx.xw = xw_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];                 // the lane's first row is byte 3 of its top group
+        cx.aw1 = (cx.xw >> 24) == q ? cx.MW1 : cx.XW1;
+        // the row above a lane's first row is the previous lane's last row: register 0; row 0 for lane 0 (score 0, length 0 in Local mode)
+        cx.DG = from_prev_lane((int)S[0], 0) + cx.aw1;
+#define P1(g) if ((uint32_t)(g) < gl_x) { uint32_t tbw; \
+            row_pass1<4 * (g) + 3>(S[4 * (g) + 3], D[4 * (g) + 3], tbw, cx, xw_lane, bs_lane); row_pass1<4 * (g) + 2>(S[4 * (g) + 2], D[4 * (g) + 2], tbw, cx, xw_lane, bs_lane); \
+            row_pass1<4 * (g) + 1>(S[4 * (g) + 1], D[4 * (g) + 1], tbw, cx, xw_lane, bs_lane); row_pass1<4 * (g)>(S[4 * (g)], D[4 * (g)], tbw, cx, xw_lane, bs_lane); \
+            tb_lane[(g) * 64] = tbw; }
+        REP20(P1)
+#undef P1
+        // ---- insertion scan across the lanes (lane-tagged DPP prefix maximum; keys are relative to the contig) --------------------
+        // The lane's first row opens from the previous lane's last row, whose NEW S' word exists only now: the loop used the
+        // placeholder word 0 for it.  The true element has the same position and a score >= 0, so its key is >= the
+        // placeholder's; combined as the EARLIER element it replaces it (scan_combine keeps the earlier one on ties).
+        const int32_t nT = from_prev_lane((int)S[0], 0);                  // S' of the previous lane's last row (lane 0: row 0)
+        ScanEl run;
+        {
+            ScanEl first; first.key = word_score(nT) + kfirst; first.q = (int32_t)word_len(nT) + qfirst;
+            ScanEl inc = scan_combine(first, cx.inc);
+            if (gl == 0) inc.key = SCAN_LOW;                              // lanes without rows
+            int32_t kt = (int32_t)(((uint32_t)inc.key << 6) | (uint32_t)(63 - lane));
+            { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 1>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 2>(INT32_MIN, kt); kt = o > kt ? o : kt; }
+            { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 4>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 8>(INT32_MIN, kt); kt = o > kt ? o : kt; }
+            { const int32_t o = dpp_mov<DPP_BCAST15, 0xA>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_BCAST31, 0xC>(INT32_MIN, kt); kt = o > kt ? o : kt; }
+            const int32_t rt = from_prev_lane(kt, INT32_MIN);             // exclusive: lanes before this one
+            run.key = rt >> 6;
+            run.q = __builtin_amdgcn_ds_bpermute((int)((63u - ((uint32_t)rt & 63u)) << 2), inc.q);
+            ScanEl seed; seed.key = SCAN_LOW; seed.q = 0;                 // I[curr][0] = MIN, length 0 (:192)
+            run = scan_combine(seed, run);
+        }
+
+        // ---- pass 2: the chain's extended bits, the insertion merge, the last column's int32 arrays; per group the lane's running
+        // records, y-suffix records and the traceback dword ------------------------------------------------------------------------------
+        Col2 c2;
+        c2.MW = MW; c2.XW = XW; c2.JSW = JSW; c2.ge = ge; c2.q = q; c2.kbase = kbase; c2.qbase = qbase; c2.bbase = bbase; c2.lbase = lbase;
+        c2.Tup = nT; c2.run = run; c2.rg4 = rg4_x;
+        c2.lastcol = (uint32_t)__builtin_amdgcn_readfirstlane(lastcol ? 1 : 0);        // (a scalar flag, not a lane mask)
+        c2.rS = __builtin_amdgcn_make_buffer_rsrc(V.S, 0, 0x7FFFFFFF, RSRC_WORD3);
+        c2.oSlen = (uint32_t)((const uint8_t*)V.Slen - (const uint8_t*)V.S); c2.oIval = (uint32_t)((const uint8_t*)V.Ival - (const uint8_t*)V.S); c2.oIlen = (uint32_t)((const uint8_t*)V.Ilen - (const uint8_t*)V.S);
+        const __amdgpu_buffer_rsrc_t rtb = __builtin_amdgcn_make_buffer_rsrc(V.tb + (size_t)(j - 1) * Rtot + roff, 0, 0x7FFFFFFF, RSRC_WORD3);
+        const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((uint8_t*)V.D + 8ull * roff, 0, 0x7FFFFFFF, RSRC_WORD3);
+        Recs R; R.bw = 0; R.xrow = 0xFFFFFFFFu; R.r1 = 0xFFFFFFFFu; R.len1 = 0;
+        const uint32_t ycol = n - j;
+        uint32_t tbw0 = 0;                                               // group 0's traceback dword (row m's byte is in it)
+        const bool mine = lane == mlane;
+        // register k of group 0 holds a row below m (a row that takes part in the records) unless this is the lane of row m and
+        // k <= pad (k < pad: no row at all; k == pad: row m itself)
+#define P2(g) if ((uint32_t)(g) < gl_x) { \
+            uint32_t tbw = tb_lane[(g) * 64]; c2.xw = xw_lane[(g) * 64]; \
+            row_pass2<4 * (g) + 3>(S[4 * (g) + 3], tbw, c2, bs_lane, !((g) == 0 && mine && 3u < pad)); row_pass2<4 * (g) + 2>(S[4 * (g) + 2], tbw, c2, bs_lane, !((g) == 0 && mine && 2u < pad)); \
+            row_pass2<4 * (g) + 1>(S[4 * (g) + 1], tbw, c2, bs_lane, !((g) == 0 && mine && 1u < pad)); row_pass2<4 * (g)>(S[4 * (g)], tbw, c2, bs_lane, !((g) == 0 && mine && 0u < pad)); \
+            const uint32_t t3 = ((g) == 0 && mine && 3u <= pad) ? 0u : S[4 * (g) + 3], t2 = ((g) == 0 && mine && 2u <= pad) ? 0u : S[4 * (g) + 2]; \
+            const uint32_t t1 = ((g) == 0 && mine && 1u <= pad) ? 0u : S[4 * (g) + 1], t0 = ((g) == 0 && mine) ? 0u : S[4 * (g)]; \
+            group_records(R, t3, t2, t1, t0, rowbase + (nrows - 4u - 4u * (g))); \
+            const uint32_t g4 = (t3 > t2 ? t3 : t2) > (t1 > t0 ? t1 : t0) ? (t3 > t2 ? t3 : t2) : (t1 > t0 ? t1 : t0); \
+            if ((int32_t)g4 >= ythr) { \
+                const uint32_t vo = 8u * (uint32_t)lane_x; \
+                if ((int32_t)t3 >= ythr) { u32x2 rec; rec.x = t3; rec.y = ycol; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, vo, (4 * (g) + 3) * 512, 0); } \
+                if ((int32_t)t2 >= ythr) { u32x2 rec; rec.x = t2; rec.y = ycol; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, vo, (4 * (g) + 2) * 512, 0); } \
+                if ((int32_t)t1 >= ythr) { u32x2 rec; rec.x = t1; rec.y = ycol; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, vo, (4 * (g) + 1) * 512, 0); } \
+                if ((int32_t)t0 >= ythr) { u32x2 rec; rec.x = t0; rec.y = ycol; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, vo, (4 * (g)) * 512, 0); } \
+            } \
+            __builtin_amdgcn_raw_buffer_store_b32(tbw, rtb, 4u * (uint32_t)lane_x, (g) * 256, AUX_NT); \
+            if ((g) == 0) tbw0 = tbw; \
+        }
+        REP20(P2)
+#undef P2
+
+        // ---- the contig's epilogue: wave reductions over rows < m, row m, the column arg-max granule --------------------------------
+        {
+            const uint32_t xw = wave_max_u32(R.bw);
+            const uint32_t xrow2 = wave_min_u32(R.bw == xw && R.xrow != 0xFFFFFFFFu ? R.xrow + 1u : 0xFFFFFFFFu);   // 1-based row
+            XsRec xb_;
+            if (xrow2 == 0xFFFFFFFFu) {
+                // no lane recorded a row: either there is no row below m (seed stays MIN, len 0), or every S word is 0 and
+                // the first row took the running value (0 > MIN, :408-417)
+                if (m > 1) { xb_.v = 0; xb_.len = 0; xb_.row = 1; } else { xb_.v = MIN_SCORE; xb_.len = 0; xb_.row = 0; }
+            }
+            else { xb_.v = (int32_t)(xw >> 16); xb_.len = xw & 0xFFFFu; xb_.row = xrow2; }
+            // column arg-max over rows 0..m-1: the first row holding the largest score; row 0 holds S = 0
+            CmRec cb_;
+            {
+                const uint32_t smax = xw >> 16;
+                const uint32_t rr1 = wave_min_u32((R.bw >> 16) == smax && R.r1 != 0xFFFFFFFFu ? R.r1 + 1u : 0xFFFFFFFFu);
+                if (smax == 0u || rr1 == 0xFFFFFFFFu) { cb_.v = 0; cb_.row = 0; cb_.len = 0; }
+                else {
+                    const unsigned long long who = __ballot(R.r1 != 0xFFFFFFFFu && R.r1 + 1u == rr1 && (R.bw >> 16) == smax);
+                    cb_.v = (int32_t)smax; cb_.row = rr1; cb_.len = (uint32_t)__builtin_amdgcn_readlane((int)R.len1, (int)__builtin_ctzll(who));
+                }
+            }
+            // ---- row m (:350-351 seeded selection, :406-447 for i == m): register `pad` of lane mlane --------------------------------
+            const uint32_t wm = pad == 0 ? S[0] : pad == 1 ? S[1] : pad == 2 ? S[2] : S[3];
+            const int32_t dgm = cx.dgm;
+            const uint32_t bytem = (tbw0 >> (8u * pad)) & 0xFFu;
+            const int32_t ownW = (int32_t)__builtin_amdgcn_readlane((int)wm, mlane);
+            const int32_t ownDG = __builtin_amdgcn_readlane(dgm, mlane);
+            const uint32_t ownByte = (uint32_t)__builtin_amdgcn_readlane((int)bytem, mlane);
+            const int32_t ownS = word_score(ownW); const uint32_t ownMv = ownByte & 7u, ownSl = word_len(ownW);
+            int32_t Sm; uint32_t Slm, mvm, lx;
+            lx = xb_.row == 0 ? 0u : m - xb_.row;
+            bool do_x_m = false;
+            if (rowm_run_wins(xb_.v, ownS, word_score(ownDG))) { Sm = xb_.v; Slm = xb_.len; mvm = MK_XSUF; }
+            else { Sm = ownS; Slm = ownSl; mvm = ownMv; if (ownSl > xb_.len) { do_x_m = true; lx = 0; } }
+            const uint32_t smw = (uint32_t)word_make(Sm, Slm);
+            if (mine) { if (pad == 0) S[0] = smw; else if (pad == 1) S[1] = smw; else if (pad == 2) S[2] = smw; else S[3] = smw; }   // the register of row m takes the seeded result
+            const uint32_t rmi = roff + m - 1;
+            if (mine) {
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(mvm | (ownByte & (TBB_IEXT | TBB_DEXT))), rtb, 4u * (uint32_t)lane + pad, 0, 0);
+                if (lastcol) { V.S[rmi] = Sm; V.Slen[rmi] = Slm; }
+                const uint32_t rl = lastcol ? (do_x_m ? ownSl : xb_.len) : 0u;
+                if (Sm >= ybase) {
+                    const uint32_t yi = pad * 64u + (uint32_t)lane;
+                    bool upd = Slm > 0u;
+                    if (lastcol) { const int32_t sn_ = word_score((int32_t)yrec[roff + yi].x); upd = Sm > sn_ || (Sm == sn_ && Slm > rl); }
+                    if (upd) { u32x2 rec; rec.x = smw; rec.y = n - j; yrec[roff + yi] = rec; }
+                }
+                V.Lx[(size_t)c * (n + 1) + j] = lx;
+            }
+            if (Sm > cb_.v) { cb_.v = Sm; cb_.row = m; cb_.len = Slm; }
+            if (cb_.v > vrun) vrun = cb_.v;
+            if (lane == 0) {
+                const unsigned long long gran = ((unsigned long long)j << 48) | ((unsigned long long)(uint32_t)(cb_.v & 0xFFFF) << 32) | ((unsigned long long)((cb_.len + 1u) & 0xFFFFu) << 16) | (cb_.row & 0xFFFFu);
+                __hip_atomic_store(xchg + (size_t)(j & 1u) * C + kmine, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // ---- unpack the y-suffix records of this wave's rows into the arrays the fix-up kernel reads (its own stores: no barrier) -------
+#pragma unroll 1
+    for (uint32_t i = 0; i < nrows; ++i) {
+        const uint32_t row = rowbase + (nrows - 1 - i);
+        if (row < m) {
+            const u32x2 rec = yrec[roff + i * 64u + (uint32_t)lane];
+            V.Sn[roff + row] = word_score((int32_t)rec.x); V.SnLen[roff + row] = word_len((int32_t)rec.x); V.Ly[roff + row] = rec.y;
+        }
+    }
+    (void)gtop;
+}
+
+uint32_t fill_regs_rows_per_wave() { return 64u * RMAX; }
+// workgroups of `waves` waves one CU holds at once, as the runtime's occupancy calculator sees it (the host never launches more
+// workgroups than CUs x this: all workgroups of a read must be resident, they wait for each other every column)
+int fill_regs_workgroups_per_cu(uint32_t waves) {
+    int n1 = 0, n4 = 0;
+    // (more than 64 KiB of dynamic LDS has to be allowed explicitly)
+    if (hipFuncSetAttribute((const void*)fill_regs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)fill_regs_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, fill_regs_kernel<1>, (int)waves * 64, (size_t)waves * LDS_PER_WAVE) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, fill_regs_kernel<4>, (int)waves * 64, (size_t)waves * LDS_PER_WAVE) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n1 < n4 ? n1 : n4;
+}
+// max_nact: the largest number of active contigs of any job of the launch
+void launch_fill_regs(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t waves, uint32_t max_nact, const FillShared& sh, hipStream_t stream) {
+    if (max_nact <= 64) hipLaunchKernelGGL(fill_regs_kernel<1>, dim3(n_jobs * G), dim3(waves * 64), (size_t)waves * LDS_PER_WAVE, stream, d_jobs, sh, G);
+    else hipLaunchKernelGGL(fill_regs_kernel<4>, dim3(n_jobs * G), dim3(waves * 64), (size_t)waves * LDS_PER_WAVE, stream, d_jobs, sh, G);
+}
+
+}  // namespace stitch

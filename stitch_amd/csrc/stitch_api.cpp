@@ -44,6 +44,10 @@ void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n
 constexpr size_t PIN_BYTES = (size_t)64 << 20;   // pinned staging buffer for result downloads
 constexpr uint32_t TILE_ROWS = 512;   // 64 lanes x 8 rows (Local-mode kernel; the generic one uses 256): contig row blocks are padded to this
 void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, uint32_t slots_cap, const FillShared& sh, hipStream_t stream);
+uint32_t fill_local16_max_slots();
+void launch_fill_regs(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t waves, uint32_t max_nact, const FillShared& sh, hipStream_t stream);
+uint32_t fill_regs_rows_per_wave();
+int fill_regs_workgroups_per_cu(uint32_t waves);
 }  // namespace stitch
 
 using namespace stitch;
@@ -73,7 +77,7 @@ struct Job {                                     // one full jump DP
 struct Knobs {
     bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false;
     size_t array_align = 0, job_align = 0;
-    int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0;
+    int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
     static Knobs from_env() {
         Knobs k;
         auto num = [](const char* name) -> unsigned long long { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : 0ull; };
@@ -83,6 +87,7 @@ struct Knobs {
         k.no_regs = getenv("STITCH_NO_REGS") != nullptr;             // keep the state-streaming kernel even where the register-resident one applies
         k.array_align = (size_t)num("STITCH_ARRAY_ALIGN"); k.job_align = (size_t)num("STITCH_JOB_ALIGN");
         k.max_waves = (int)num("STITCH_MAX_WAVES"); k.wg_per_read = (int)num("STITCH_WG_PER_READ"); k.tiles_per_wave = (int)num("STITCH_TILES_PER_WAVE");
+        if (const char* e = getenv("STITCH_REGS_MIN_ROWS")) k.regs_min_rows = atol(e);     // (tests: 0 sends every eligible read to fill_regs.hip)
         return k;
     }
 };
@@ -114,6 +119,7 @@ struct stitch_ctx {
     std::vector<long> per_read;                  // read -> index into job_chains, -1 = none; for stitch_format_sam
     stitch_timing tm{};
     int n_cus = 256; uint32_t tm_wg_per_read = 1;
+    int regs_wg_per_cu = 0;                      // workgroups of fill_regs.hip one CU holds at once (occupancy query; 0: kernel unusable)
     bool tm_fast = false;                        // last run_jobs used the Local-mode 16-bit kernel
     size_t mem_limit = 0;                        // optional cap on arena bytes (STITCH_ARENA_BYTES), for tests
     // banded pre-alignment filter (prealign.h): host copies of the contig strands, their k-mer indexes, device scratch
@@ -308,6 +314,7 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     }
     if (const char* lim = getenv("STITCH_ARENA_BYTES")) c->mem_limit = (size_t)strtoull(lim, nullptr, 10);
     c->knobs = Knobs::from_env();
+    c->regs_wg_per_cu = fill_regs_workgroups_per_cu(4);
     *out = c.release();
     return STITCH_OK;
 }
@@ -367,6 +374,22 @@ bool local16_ok(const stitch_ctx& c, const Job& jb) {
     if (tiles > 2048u * 16u) return false;                // the kernel's per-workgroup slot table (fill_local16.hip MAXSLOTS) at G <= 16
     return o.mode == 0 && o.gap_open + o.gap_extend < 0 && (long long)std::max(o.match_score, 0) * n <= 32767 &&
            n + (long long)c.max_m + 2 <= 65535 && lo >= -16000 && o.match_score <= 16000;
+}
+
+// The register-resident Local-mode kernel (fill_regs.hip): one wave per active contig, REGS_WAVES waves per workgroup.  Returns the
+// workgroups a read needs (0: not applicable — circular contigs, a contig longer than a wave holds, a gap-extension penalty
+// too large for lane-tagged scan keys, more workgroups than the device holds at once, or a read too small to be worth a team).
+constexpr uint32_t REGS_WAVES = 4;
+uint32_t regs_plan(const stitch_ctx& c, const Job& jb) {
+    if (c.knobs.no_regs || c.regs_wg_per_cu <= 0 || !local16_ok(c, jb) || c.opts.circular) return 0;
+    if (c.opts.gap_extend < -4096) return 0;
+    uint64_t rows = 0;
+    for (uint32_t a : jb.act) { if (c.al[a].m > fill_regs_rows_per_wave()) return 0; rows += c.al[a].m; }
+    const uint64_t min_rows = c.knobs.regs_min_rows >= 0 ? (uint64_t)c.knobs.regs_min_rows : 2048u;
+    if (rows < min_rows) return 0;
+    const uint32_t G = ((uint32_t)jb.act.size() + REGS_WAVES - 1) / REGS_WAVES;
+    if (G > (uint32_t)c.n_cus * (uint32_t)c.regs_wg_per_cu) return 0;
+    return G;
 }
 
 constexpr int MAX_WAVES_GENERIC = 8;               // fill_kernel.hip: __launch_bounds__(512)
@@ -438,7 +461,11 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         // (reads that get ONE workgroup each do not wait for anybody, so any number of them shares a launch)
         if (c.knobs.wg_per_read) gd_min = (uint32_t)c.knobs.wg_per_read;          // (experiments)
-        const size_t win = (all_fast && gd_min > 1) ? std::min<size_t>(jobs.size(), (size_t)std::max(1, c.n_cus) / gd_min) : jobs.size();
+        // (the register-resident kernel gives a read regs_plan() workgroups, all resident at once)
+        uint32_t rg_min = 0xFFFFFFFFu;
+        if (all_fast) for (const Job& jb : jobs) rg_min = std::min(rg_min, regs_plan(c, jb));
+        size_t win = (all_fast && gd_min > 1) ? std::min<size_t>(jobs.size(), (size_t)std::max(1, c.n_cus) / gd_min) : jobs.size();
+        if (all_fast && rg_min > 0 && rg_min != 0xFFFFFFFFu) win = std::min<size_t>(jobs.size(), std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs_wg_per_cu / rg_min));
         size_t cur = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
             cur += lay[k].stride + sizeof(JobView) + sizeof(WalkArgs) + 512;
@@ -487,7 +514,9 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         // workgroup's slot table holds 2048 tiles.
         size_t max_jobs = 4096;
         uint32_t g_min = 1;
-        if (fast) {
+        const uint32_t regs_G = fast ? regs_plan(c, jobs[k0]) : 0u;       // > 0: this launch runs the register-resident kernel
+        if (regs_G) max_jobs = std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs_wg_per_cu / regs_G);      // every workgroup of the launch resident at once
+        else if (fast) {
             uint32_t tiles = 0; for (uint32_t a : jobs[k0].act) tiles += (c.al[a].m + 255) / 256;
             g_min = std::max(1u, (tiles + 2047) / 2048);
             // at least 4 workgroups per read: measured best on cfg2 (64 reads x 4 beats 85 x 3 by 15 %: shorter columns per
@@ -502,7 +531,8 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             if (c.knobs.wg_per_read) max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, (uint32_t)c.knobs.wg_per_read));
         }
         const size_t per_job = sizeof(JobView) + sizeof(WalkArgs) + 512;     // the launch's job table, after the jobs' own buffers
-        while (k1 < jobs.size() && used + lay[k1].stride + per_job + view_room <= c.arena_bytes && (k1 - k0) < max_jobs) { used += lay[k1].stride + per_job; ++k1; }
+        while (k1 < jobs.size() && used + lay[k1].stride + per_job + view_room <= c.arena_bytes && (k1 - k0) < max_jobs &&
+               (k1 == k0 || regs_plan(c, jobs[k1]) == regs_G || !fast)) { used += lay[k1].stride + per_job; ++k1; }
         if (k1 == k0) return fail(STITCH_ENOMEM, "arena too small for one job");
         const uint32_t nj = (uint32_t)(k1 - k0);
         std::vector<JobView> views(nj); std::vector<WalkArgs> wargs(nj);
@@ -543,7 +573,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             memcpy(stg + (L.off_cd - L.off_y), cd.data(), sizeof(ContigDesc) * (size_t)c.C);
             HIP_TRY(hipMemcpyAsync(B + L.off_y, stg, L.off_hdr - L.off_y, hipMemcpyHostToDevice, c.stream));
             JobView& V = views[q];
-            V.tb_keyfmt = fast ? 1u : 0u;
+            V.tb_keyfmt = regs_G ? 2u : fast ? 1u : 0u; V.yrec_global = jb.mode == 0 ? 1u : 0u;
             V.P = c.P; V.n = L.n; V.C = c.C; V.nact = L.nact; V.Rtot = L.Rj;
             V.act = (const uint32_t*)(B + L.off_act); V.opp_act = (const int32_t*)(B + L.off_opp); V.cd = (const ContigDesc*)(B + L.off_cd);
             V.xseq = c.d_xseq; V.y = B + L.off_y;
@@ -575,7 +605,8 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         // workgroups per read for the Local-mode kernel: fill the CUs, but keep every workgroup resident at once (they
         // wait for each other every column) and leave each at least a couple of contigs
         uint32_t G = 1;
-        if (fast) {
+        if (regs_G) G = regs_G;
+        else if (fast) {
             uint32_t min_act = 0xFFFFFFFFu;
             for (uint32_t q = 0; q < nj; ++q) min_act = std::min(min_act, lay[k0 + q].nact);
             const uint32_t cus = (uint32_t)c.n_cus;
@@ -599,15 +630,16 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             waves = (int)std::max(1u, std::min<uint32_t>(MAX_WAVES_LOCAL, min_tiles / tpw));
             if (c.knobs.max_waves) waves = std::max(1, std::min(waves, c.knobs.max_waves));
         }
-        c.tm_wg_per_read = G; c.tm.wg_per_read = G; c.tm.fill_kind = fast ? 1u : 0u;
+        c.tm_wg_per_read = G; c.tm.wg_per_read = G; c.tm.fill_kind = regs_G ? 2u : fast ? 1u : 0u;
         uint32_t slots_cap = 0;                          // tiles of the launch's largest workgroup (contigs are dealt round-robin to a read's G workgroups)
-        if (fast) for (uint32_t q = 0; q < nj; ++q) {
+        if (fast && !regs_G) for (uint32_t q = 0; q < nj; ++q) {
             std::vector<uint32_t> per(G, 0);
             const std::vector<uint32_t>& act = jobs[k0 + q].act;
             for (size_t k = 0; k < act.size(); ++k) per[k % G] += (c.al[act[k]].m + 255) / 256;
             for (uint32_t v : per) slots_cap = std::max(slots_cap, v);
         }
-        if (fast) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, c.stream);
+        if (regs_G) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, nj, G, REGS_WAVES, mx, sh, c.stream); }
+        else if (fast) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, c.stream);
         else launch_fill(d_views, nj, waves, sh, c.stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev[1], c.stream));

@@ -24,10 +24,13 @@ struct ChainHdr {              // == Alignment (align/alignment.rs:16-51)
     uint32_t start_contig_idx, end_contig_idx, length, n_ops, status;   // status: 0 ok, 1 None, 2 overflow, 3 bad move / runaway, 4 reference-undefined XJUMP
 };
 
+constexpr int REGS_RMAX = 80;  // fill_regs.hip: rows a lane holds in registers (a wave owns one contig of up to 64 x REGS_RMAX rows)
+
 struct JobView {
     DpParams P;
     uint32_t n, C, nact, Rtot;
-    uint32_t tb_keyfmt;        // 1: traceback bytes are in the Local-mode kernel's key format
+    uint32_t tb_keyfmt;        // 1: traceback bytes are in the Local-mode kernels' key format; 2: key format, lane-interleaved rows (fill_regs.hip)
+    uint32_t yrec_global;      // fill_regs.hip: y-suffix records only for cells that reach the best score of ANY contig so far (mode traceback)
     const uint32_t* act;       // active aligner ids in aligner order (the reference's `self.contigs` after sub-setting)
     const int32_t* opp_act;    // [C] opposite-strand aligner id if both strands are active, else -1
     const ContigDesc* cd;      // [C]
@@ -78,10 +81,24 @@ STITCH_HD void decode_src(const JobView& V, uint32_t c, uint32_t i, uint32_t j, 
         default: idx = V.jt_idx[(size_t)c * (V.n + 1) + j] & ~JT_CIRC_BIT; from = V.jt_from[(size_t)c * (V.n + 1) + j]; break;   // MV_JUMP
     }
 }
+// Where the traceback byte of row i (1-based) of a contig of m rows sits within a column's bytes of that contig.  The tiled
+// kernels store rows linearly.  fill_regs.hip stores them lane-interleaved: lane l of the contig's wave holds a run of
+// r = ceil(m / 64) consecutive rows (r - 1 for the lanes from a = m - 64 (r - 1) on) in registers r-1 .. 0, top to bottom, and
+// register idx of lane l goes to byte ((idx >> 2) * 64 + l) * 4 + (idx & 3), so that one store instruction writes whole lines.
+STITCH_HD uint32_t tb_row_offset(uint32_t keyfmt, uint32_t m, uint32_t i) {
+    if (keyfmt != 2) return i - 1;
+    const uint32_t r = (m + 63) / 64, a = m - 64 * (r - 1), row = i - 1;
+    uint32_t lane, uu;
+    if (row < a * r) { lane = row / r; uu = row - lane * r; }
+    else { const uint32_t q = row - a * r; lane = a + q / (r - 1); uu = q - (lane - a) * (r - 1); }
+    const uint32_t idx = r - 1 - uu;
+    return ((idx >> 2) * 64 + lane) * 4 + (idx & 3);
+}
+
 // Traceback byte of cell (i,j) in the generic move codes.  The Local-mode kernel writes key-format bytes (dp_core.h)
 // and flags "row 1 took the circular jump" in bit 31 of the column's jump-table entry.
 STITCH_HD uint32_t tb_byte(const JobView& V, uint32_t c, uint32_t i, uint32_t j) {
-    const uint32_t raw = V.tb[(size_t)(j - 1) * V.Rtot + V.cd[c].roff + i - 1];
+    const uint32_t raw = V.tb[(size_t)(j - 1) * V.Rtot + V.cd[c].roff + tb_row_offset(V.tb_keyfmt, V.cd[c].m, i)];
     if (!V.tb_keyfmt) return raw;
     return key_code_to_generic(raw, i == 1 && (V.jt_idx[(size_t)c * (V.n + 1) + j] & JT_CIRC_BIT) != 0);
 }

@@ -1,0 +1,91 @@
+"""The register-resident Local-mode kernel (stitch_amd/csrc/fill_regs.hip) against the golden vectors and the oracle.
+
+By default only reads with at least 2048 active contig rows go to it (smaller ones run fill_local16.hip), so the parity suite's
+small cases would never reach it: here STITCH_REGS_MIN_ROWS=0 sends EVERY eligible read to it (Local mode, not circular,
+contigs of at most 5120 rows) and the scenarios of tests/test_gpu_parity.py are replayed.  Contig lengths around the lane
+mapping's edges (1 row, 3, 4, 5, 255..257, 1300 rows: groups of four rows dealt to 64 lanes) get a test of their own."""
+import random
+
+import pytest
+
+import stitch_amd
+from stitch_amd import synth
+from tests import test_gpu_parity as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def every_eligible_read_to_the_register_kernel(monkeypatch):
+    monkeypatch.setenv("STITCH_REGS_MIN_ROWS", "0")
+
+
+def test_the_register_kernel_is_the_one_that_runs():
+    db = synth.make_db(5, 700, 3)
+    al = stitch_amd.Builder().build_aligners([stitch_amd.TargetSeq(n, s) for n, s in db])
+    al.align(synth.make_reads(db, 4, 300, 5))
+    tm = al.timing()
+    assert tm["fill_kind"] == 2 and tm["wg_per_read"] == 2          # 5 contigs: two workgroups of four waves
+
+
+def test_golden_single_contig():
+    P.test_golden_single_contig()
+
+
+def test_golden_multi_contig():
+    P.test_golden_multi_contig()
+
+
+def test_golden_jump_score_priorities():
+    P.test_golden_jump_score_priorities()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_options_vs_oracle(seed):
+    P.test_random_options_vs_oracle(seed)
+
+
+def test_cfg1_shape_150bp_vs_5kb_plasmid():
+    P.test_cfg1_shape_150bp_vs_5kb_plasmid()
+
+
+def test_multi_tile_contigs_and_long_reads():
+    P.test_multi_tile_contigs_and_long_reads()
+
+
+@pytest.mark.parametrize("batch", [1, 3, 40])
+def test_ragged_contig_lengths(batch):
+    rng = random.Random(11 + batch)
+    lens = [1, 2, 3, 4, 5, 255, 256, 257, 511, 513, 40, 1300, 7, 64, 65, 63]
+    targets = [(f"c{k}", P.rand_seq(rng, n)) for k, n in enumerate(lens)]
+    reads = [P.chimera(rng, [t for t in targets if len(t[1]) > 30], rng.randint(30, 500), both=True) for _ in range(batch)]
+    P.run_pair(targets, reads, double_strand=True, check_sam=False)
+    P.run_pair(targets[:4], reads[:2], check_sam=False)
+    P.run_pair(targets, reads[:3], suboptimal=True, check_sam=False)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_scoring_at_the_limits_of_the_16_bit_kernel(seed):
+    P.test_scoring_at_the_limits_of_the_16_bit_kernel(seed)
+
+
+def test_more_than_64_active_contigs():
+    """granule records in more than one register per lane (fill_regs_kernel<4>), many workgroups per read"""
+    db = synth.make_db(120, 150, 1002)
+    targets = [(n, s.decode()) for n, s in db]
+    reads = [r.decode() for r in synth.make_reads(db, 5, 400, 47, sub=0.01, ins=0.005, dele=0.005)]
+    P.run_pair(targets, reads, suboptimal=True)
+    P.run_pair(targets, reads[:2], double_strand=True, check_sam=False)
+
+
+def test_iupac_codes_n_and_lower_case():
+    P.test_iupac_codes_n_and_lower_case()
+
+
+def test_long_contigs_near_the_register_capacity():
+    """contigs of 4990..5120 rows (79-80 rows per lane), both strands, chimeric reads of a few hundred columns"""
+    rng = random.Random(21)
+    targets = [(f"c{k}", P.rand_seq(rng, n)) for k, n in enumerate([5120, 5000, 4991, 5119, 3000])]
+    reads = [P.chimera(rng, targets, rng.randint(150, 400), both=True) for _ in range(6)]
+    P.run_pair(targets, reads, double_strand=True)
+    P.run_pair(targets, reads[:3], suboptimal=True, check_sam=False)
