@@ -82,16 +82,18 @@ STITCH_HD void decode_src(const JobView& V, uint32_t c, uint32_t i, uint32_t j, 
     }
 }
 // Where the traceback byte of row i (1-based) of a contig of m rows sits within a column's bytes of that contig.  The tiled
-// kernels store rows linearly.  fill_regs.hip stores them lane-interleaved: lane l of the contig's wave holds a run of
-// r = ceil(m / 64) consecutive rows (r - 1 for the lanes from a = m - 64 (r - 1) on) in registers r-1 .. 0, top to bottom, and
-// register idx of lane l goes to byte ((idx >> 2) * 64 + l) * 4 + (idx & 3), so that one store instruction writes whole lines.
+// kernels store rows linearly.  fill_regs.hip stores them lane-interleaved: the contig's ceil(m / 4) groups of four rows are
+// dealt to the 64 lanes of its wave in order (the first `grem` lanes hold one group more), a lane's rows fill its registers
+// nrows-1 .. 0 top to bottom, and register idx of lane l goes to byte ((idx >> 2) * 64 + l) * 4 + (idx & 3), so that one store
+// instruction writes whole lines.
 STITCH_HD uint32_t tb_row_offset(uint32_t keyfmt, uint32_t m, uint32_t i) {
     if (keyfmt != 2) return i - 1;
-    const uint32_t r = (m + 63) / 64, a = m - 64 * (r - 1), row = i - 1;
-    uint32_t lane, uu;
-    if (row < a * r) { lane = row / r; uu = row - lane * r; }
-    else { const uint32_t q = row - a * r; lane = a + q / (r - 1); uu = q - (lane - a) * (r - 1); }
-    const uint32_t idx = r - 1 - uu;
+    const uint32_t ngr = (m + 3) / 4, gq = ngr / 64, grem = ngr % 64, row = i - 1;
+    const uint32_t big = 4 * (gq + 1), small = 4 * gq;
+    uint32_t lane, uu, nrows;
+    if (row < grem * big) { lane = row / big; uu = row - lane * big; nrows = big; }
+    else { const uint32_t rr = row - grem * big; lane = grem + rr / small; uu = rr - (lane - grem) * small; nrows = small; }
+    const uint32_t idx = nrows - 1 - uu;
     return ((idx >> 2) * 64 + lane) * 4 + (idx & 3);
 }
 
@@ -291,7 +293,7 @@ STITCH_HD void walk_from_t(const JobView& V, uint32_t contig_index, ChainHdr& H,
         ++nops;
     };
     for (;;) {
-        if (++steps > max_steps) { H.status = 3; break; }
+        if (++steps > max_steps || i > V.cd[cur].m || j > n) { H.status = 3; break; }     // (a walk that leaves the matrix ends with an error, not a fault)
         // (cur is checked against the active set where it changes: at the start and after every jump)
         uint32_t next_layer;
         if (last_layer == TB_START) break;
