@@ -41,22 +41,34 @@ constexpr int AUX_NT = 2;                      // streamed once: non-temporal
 // best{diagonal, deletion} (pass 1 -> the insertion merge of pass 2)
 constexpr uint32_t LDS_XW = 0, LDS_TB = NG * 64 * 4, LDS_BS = 2 * NG * 64 * 4, LDS_PER_WAVE = 2 * NG * 64 * 4 + RMAX * 64 * 2;
 
+// The insertion chain I[i] = max(I[i-1] + ge, S'[i-1] + go + ge) (single_contig_aligner.rs:314-326; S' = S without its own
+// insertion candidate, dp_core.h phase B) is carried as a WORD like S and D (score << 16 | length): one step down a lane is
+//   ext = I + GE1, open = S'(row above) + GO1, I = score(ext) >= score(open) ? ext : open     (the extension wins ties, :321)
+// i.e. two adds, a compare of the high halves and a select.  Every row has an opener with score >= go + ge (S' >= 0), so the
+// chain's score stays >= go + ge + ge and the 16-bit field cannot wrap (regs_plan: ge >= -1024, go + ge >= -8000).  Pass 1 runs
+// the chain of the lane's OWN openers only (what arrives from the lanes above is not known yet); its value behind the lane's
+// last row crosses the lanes as a position-normalised key in a lane-tagged DPP prefix maximum; pass 2 runs the true chain.
+constexpr int32_t CHAIN_NONE = (int32_t)0x92A00000u;      // word(-28000, 0): "no chain yet", cannot wrap when extended
+constexpr int32_t CHAIN_JUNK_T = (int32_t)0xC1800000u;    // word(-16000, 0): stands in for the unknown row above a lane's first row
+
+__device__ __forceinline__ int32_t chain_step(const int32_t I, const int32_t Tabove, const int32_t GE1, const int32_t GO1) {
+    const int32_t ext = I + GE1, open = Tabove + GO1;
+    return word_score(ext) >= word_score(open) ? ext : open;
+}
+
 // wave-uniform values of one contig's column, and the lane's rolling values of the row loop of pass 1
 struct Col {
     int32_t MW1, XW1, GE1, GO1, JSWm1;         // (match, mismatch) << 16 | 1; gap words; the column's jump word minus one length unit
     uint32_t q;                                // y[j-1]
-    int32_t ge;
-    int32_t kbase, qbase;                      // per lane: scan key / length terms of register 0 (register IDX adds ge * IDX / IDX)
     int32_t aw1, DG;                           // the current row's (match | mismatch) word and diagonal candidate: old S word of the row above + aw1
     uint32_t xw;                               // four bases: the group of the NEXT row
-    int32_t Tup;                               // new S' word of the row above (insertion scan)
-    ScanEl inc;                                // the lane's running scan element (earliest opener wins ties)
+    int32_t Tup;                               // new S' word of the row above
+    int32_t Iw;                                // insertion chain of the lane's own openers, arriving at the current row
     int32_t dgm; uint32_t pad;                 // row m (register `pad` of its lane): its diagonal candidate, needed for its finalisation
 };
 
 // ---- pass 1, one row (register IDX): everything of the cell that needs column j-1 only (dp_core.h row_phase_a_word), written
-// in place; the row's scan element joins the lane's running one; the score of best{diagonal, deletion} is parked in LDS for
-// the insertion merge of pass 2
+// in place; the score of best{diagonal, deletion} is parked in LDS for the insertion merge of pass 2
 template <int IDX>
 __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32_t& tbw, Col& c, const uint32_t* xw_lane, uint16_t* bs_lane) {
     constexpr int k = IDX & 3;
@@ -71,12 +83,11 @@ __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32
         c.DG = Sold + c.aw1;                                 // diagonal: score + a, length + 1
     }
     const int32_t DE = Dold + c.GE1, DO = Sold + c.GO1;
-    const bool dext = (DE | 0xFFFF) >= DO;                   // the extension wins ties (:332)
+    const bool dext = word_score(DE) >= word_score(DO);      // the extension wins ties (:332)
     const int32_t BD = dext ? DE : DO;
-    const int32_t DGh = DG | 0xFFFF, BDh = BD | 0xFFFF;
-    const bool c1 = BD > DGh;                                // deletion strictly better than the diagonal
+    const bool c1 = word_score(BD) > word_score(DG);         // deletion strictly better than the diagonal
     const int32_t bs2 = c1 ? BD : DG;
-    const int32_t X = c1 ? BDh : DG;                         // what the jump has to beat (:373-382)
+    const int32_t X = c1 ? (BD | 0xFFFF) : DG;               // what the jump has to beat (:373-382)
     const int32_t JW = aw1 + c.JSWm1;
     const bool c3 = JW > X;
     int32_t T = c3 ? JW : bs2;
@@ -86,61 +97,54 @@ __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32
     tbw = k == 3 ? code : ((tbw << 8) | code);               // byte k of the group's dword: register 4g+3 first, 4g last
     bs_lane[IDX * 64] = (uint16_t)((uint32_t)bs2 >> 16);
     if (IDX < 4) { if (c.pad == (uint32_t)IDX) c.dgm = DG; }
-    // insertion scan element of this row: opened from the row above (key_i = S'(i-1) + go + ge - ge * i, q_i = S'.len(i-1) + 1 - i,
-    // i = the row's 1-based index in the contig)
-    ScanEl el; el.key = word_score(c.Tup) + (c.kbase + c.ge * IDX); el.q = (int32_t)word_len(c.Tup) + (c.qbase + IDX);
-    c.inc = scan_combine(c.inc, el);
+    c.Iw = chain_step(c.Iw, c.Tup, c.GE1, c.GO1);           // ... arriving at this row (unused here), and on to the next below
     c.Tup = T;
     Sreg = (uint32_t)T; Dreg = (uint32_t)BD;
 }
 
 struct Col2 {
-    int32_t MW, XW, JSW, ge; uint32_t q;
-    int32_t kbase, qbase, bbase, lbase;        // per lane: key / length terms as in pass 1; I score = run.key + bbase - ge * IDX, I length = run.q + lbase - IDX
-    uint32_t xw; int32_t Tup;
-    ScanEl run;                                // the chain's value before the current row
+    int32_t MW, XW, JSW, GE1, GO1; uint32_t q;
+    uint32_t xw;
+    int32_t Iw;                                // the insertion chain's word AT the current row ...
+    uint32_t extn;                             // ... and TBB_IEXT if it got there by an extension (else 0)
     uint32_t lastcol; uint32_t rg4;            // j == n; 4 x (index of register 0's row in the job's linear row arrays)
     __amdgpu_buffer_rsrc_t rS; uint32_t oSlen, oIval, oIlen;          // the last column's int32 arrays: one descriptor, byte offsets from V.S
 };
 
-// ---- pass 2, one row: the chain's "extended" bit, and the merge of the insertion into the cell where it changes it
-// (dp_core.h row_phase_c_word: beats best{diagonal, deletion}, is not beaten by the jump)
+// ---- pass 2, one row: the merge of the insertion into the cell where it changes it (dp_core.h row_phase_c_word: beats
+// best{diagonal, deletion}, is not beaten by the jump), the chain's "extended" bit, and the chain's step to the next row
 template <int IDX>
 __device__ __forceinline__ void row_pass2(uint32_t& Sreg, uint32_t& tbw, Col2& c, const uint16_t* bs_lane, const bool real) {
     constexpr int k = IDX & 3;
-    ScanEl el; el.key = word_score(c.Tup) + (c.kbase + c.ge * IDX); el.q = (int32_t)word_len(c.Tup) + (c.qbase + IDX);
-    const bool ext = c.run.key >= el.key;
-    if (!ext) c.run = el;
-    const int32_t bi = c.run.key + (c.bbase - c.ge * IDX);
-    const int32_t T = (int32_t)Sreg;
-    uint32_t byte = (tbw >> (8 * k)) & 0xFFu;
-    byte |= ext ? (uint32_t)TBB_IEXT : 0u;
-    const int32_t bih = (int32_t)(((uint32_t)bi << 16) | 0xFFFFu);
+    const int32_t T = (int32_t)Sreg, Iw = c.Iw;
+    tbw |= c.extn << (8 * k);
     // the insertion can only change the cell if its score reaches the cell's (T >= 0, so a negative insertion never does)
     int32_t Tn = T;
-    if (__ballot(bi >= 0 && bih >= T) != 0ull) {
-        const uint32_t il = (uint32_t)(c.run.q + (c.lbase - IDX));
+    if (__builtin_expect(__ballot((Iw | 0xFFFF) >= T) != 0ull, 0)) {
+        const int32_t bi = word_score(Iw); const uint32_t il = word_len(Iw);
         const uint32_t xb = (c.xw >> (8 * k)) & 0xFFu;
         RowW ra;
-        ra.T = T; ra.mvT = byte & 7u;
+        ra.T = T; ra.mvT = (tbw >> (8 * k)) & 7u;
         ra.JW = c.JSW + (xb == c.q ? c.MW : c.XW);
         ra.bs2h = (int32_t)(((uint32_t)bs_lane[IDX * 64] << 16) | 0xFFFFu);
         uint32_t mv;
         Tn = row_phase_c_word(ra, bi, il, mv);
-        byte = (byte & ~7u) | mv;
+        tbw = (tbw & ~(7u << (8 * k))) | (mv << (8 * k));
     }
-    if (c.lastcol != 0u) {
+    if (__builtin_expect(c.lastcol != 0u, 0)) {
         // column n: the int32 arrays the fix-up kernel reads (single_contig_aligner.rs:453-555)
         if (real) {
-            const uint32_t il = (uint32_t)(c.run.q + (c.lbase - IDX));
             const uint32_t vo = c.rg4 - 4u * IDX;
             __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score(Tn), c.rS, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len(Tn), c.rS, vo, c.oSlen, 0);
-            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)bi, c.rS, vo, c.oIval, 0); __builtin_amdgcn_raw_buffer_store_b32(il, c.rS, vo, c.oIlen, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score(Iw), c.rS, vo, c.oIval, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len(Iw), c.rS, vo, c.oIlen, 0);
         }
     }
-    tbw = (tbw & ~(0xFFu << (8 * k))) | (byte << (8 * k));
     Sreg = (uint32_t)Tn;
-    c.Tup = T;                                  // the scan runs on S WITHOUT its own insertion candidate (dp_core.h, phase B)
+    // the chain's step to the row below: it opens from S WITHOUT its own insertion candidate (dp_core.h, phase B) = T
+    const int32_t ext = Iw + c.GE1, open = T + c.GO1;
+    const bool isext = word_score(ext) >= word_score(open);
+    c.Iw = isext ? ext : open;
+    c.extn = isext ? (uint32_t)TBB_IEXT : 0u;
 }
 
 // the lane's running records over a contig's column (rows below m): the largest S word and the topmost row holding it (x-suffix
@@ -207,6 +211,8 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     const gptr<const uint8_t> yseq = as_global(V.y);
     const gptr<u32x2> yrec = (gptr<u32x2>)as_global(V.D);      // [Rtot] 8-byte records: D and Dlen are contiguous (layout_job)
     const gptr<unsigned long long> xchg = as_global(V.xchg);
+    const gptr<uint32_t> jt_idx = as_global(V.jt_idx), jt_from = as_global(V.jt_from), Lx = as_global(V.Lx);
+    uint8_t* const tb0 = V.tb + roff;
     const bool ymode_global = V.yrec_global != 0;
     // register IDX of this lane holds the contig's row (1-based) pos1 = rowbase + nrows - IDX
     const int32_t pos1_0 = (int32_t)(rowbase + nrows);                  // ... of register 0
@@ -243,16 +249,21 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     int32_t vrun = sh.base0[c].score;                                     // the contig's running maximum over columns < j
     int32_t gmax = 0;                                                     // best score of any contig in columns < j (row 0 holds 0)
     // the contigs' column arg-max of column j-1, lane l holding active contigs l, l + 64, ...: {column, score, len, from} granules
-    unsigned long long gv[NQ];
+    unsigned long long gv[NQ]; uint32_t actid[NQ];      // ... and their aligner ids
 #pragma unroll
-    for (int qq = 0; qq < NQ; ++qq) gv[qq] = 0ull;
+    for (int qq = 0; qq < NQ; ++qq) { gv[qq] = 0ull; actid[qq] = 0u; }
 #pragma unroll
     for (int qq = 0; qq < NQ; ++qq) {
         const uint32_t k = (uint32_t)lane + 64u * qq;
+        if (k < nact) actid[qq] = V.act[k];
         if (k < nact) { const JumpBase b = sh.base0[V.act[k]]; gv[qq] = ((unsigned long long)(uint32_t)(b.score & 0xFFFF) << 32) | ((unsigned long long)(b.len & 0xFFFFu) << 16) | (b.from & 0xFFFFu); gmax = b.score > gmax ? b.score : gmax; }
     }
     gmax = (int32_t)wave_max_u32((uint32_t)gmax);
 
+    // descriptors of the arrays written with buffer stores (scalar base + lane offset: no address arithmetic in vector registers)
+    const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((uint8_t*)V.D + 8ull * roff, 0, 0x7FFFFFFF, RSRC_WORD3);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(V.S, 0, 0x7FFFFFFF, RSRC_WORD3);
+    const uint32_t oSlen = (uint32_t)((const uint8_t*)V.Slen - (const uint8_t*)V.S), oIval = (uint32_t)((const uint8_t*)V.Ival - (const uint8_t*)V.S), oIlen = (uint32_t)((const uint8_t*)V.Ilen - (const uint8_t*)V.S);
     uint32_t ychunk = 0;
     for (uint32_t j = 1; j <= n; ++j) {
         const bool lastcol = j == n;
@@ -292,6 +303,13 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)(k & 63u)), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)(k & 63u));
             return ((unsigned long long)hi << 32) | lo;
         };
+        auto act_of = [&](uint32_t k) -> uint32_t {
+            const uint32_t w = k >> 6;
+            uint32_t v = actid[0];
+#pragma unroll
+            for (int qq = 1; qq < NQ; ++qq) v = w == (uint32_t)qq ? actid[qq] : v;
+            return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(k & 63u));
+        };
         JumpInfo ji;
         {
             unsigned long long ik = 0;
@@ -305,13 +323,13 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             }
             ik = wave_max_u64(ik);
             { const unsigned long long b = rec_of(kmine); ji.score = (int32_t)((b >> 32) & 0xFFFFu) + jump_same; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = c; ji.from = (uint32_t)b & 0xFFFFu; }
-            if (kopp >= 0) { const unsigned long long b = rec_of((uint32_t)kopp); const int32_t sc = (int32_t)((b >> 32) & 0xFFFFu) + jump_opp; if (sc > ji.score) { ji.score = sc; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = V.act[kopp]; ji.from = (uint32_t)b & 0xFFFFu; } }
+            if (kopp >= 0) { const unsigned long long b = rec_of((uint32_t)kopp); const int32_t sc = (int32_t)((b >> 32) & 0xFFFFu) + jump_opp; if (sc > ji.score) { ji.score = sc; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = act_of((uint32_t)kopp); ji.from = (uint32_t)b & 0xFFFFu; } }
             if (ik != 0) {
                 const uint32_t kw = (uint32_t)(ik & 0xFFFFu) - 1; const unsigned long long b = rec_of(kw);
                 const int32_t sc = (int32_t)((b >> 32) & 0xFFFFu) + jump_inter;
-                if (sc > ji.score) { ji.score = sc; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = V.act[kw]; ji.from = (uint32_t)b & 0xFFFFu; }
+                if (sc > ji.score) { ji.score = sc; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = act_of(kw); ji.from = (uint32_t)b & 0xFFFFu; }
             }
-            if (lane == 0) { V.jt_idx[(size_t)c * (n + 1) + j] = ji.idx; V.jt_from[(size_t)c * (n + 1) + j] = ji.from; }
+            if (lane == 0) { jt_idx[(size_t)c * (n + 1) + j] = ji.idx; jt_from[(size_t)c * (n + 1) + j] = ji.from; }
         }
         const int32_t JSW = __builtin_amdgcn_readfirstlane(word_make(ji.score, ji.len));
         // y-suffix records are kept for cells whose score reaches ybase (never for a zero word)
@@ -321,8 +339,6 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         // (what depends only on the lane is constant over the read: the compiler would hoist the base words and the group guards out
         // of the column loop and pin registers for them; values it cannot see through keep them one LDS read / one compare each)
         int lane_x = lane; uint32_t gl_x = gl; int32_t pos_x = pos1_0; asm volatile("" : "+v"(lane_x), "+v"(gl_x), "+v"(pos_x));
-        const int32_t kbase = kb0 - ge * pos_x, qbase = 1 - pos_x, bbase = ge * pos_x, lbase = pos_x;
-        const int32_t kfirst = kbase + ge * (4 * (int32_t)gl_x - 1), qfirst = qbase + 4 * (int32_t)gl_x - 1;       // the same for the lane's first row
         const uint32_t rg4_x = 4u * (roff + (uint32_t)pos_x - 1u);       // 4 x (linear row index of register 0's row)
         const uint32_t* const xw_lane = (const uint32_t*)(s_wave + LDS_XW) + lane_x;
         uint32_t* const tb_lane = (uint32_t*)(s_wave + LDS_TB) + lane_x;
@@ -330,9 +346,9 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
 
         // ---- pass 1: rows top to bottom = registers 4 gl - 1 .. 0 ------------------------------------------------------------------
         Col cx;
-        cx.MW1 = MW + 1; cx.XW1 = XW + 1; cx.GE1 = GE1; cx.GO1 = GO1; cx.JSWm1 = JSW - 1; cx.q = q; cx.ge = ge; cx.kbase = kbase; cx.qbase = qbase;
-        cx.Tup = 0;                                                       // (placeholder for the lane's first row: see below)
-        cx.inc.key = SCAN_LOW; cx.inc.q = 0;
+        cx.MW1 = MW + 1; cx.XW1 = XW + 1; cx.GE1 = GE1; cx.GO1 = GO1; cx.JSWm1 = JSW - 1; cx.q = q;
+        cx.Tup = CHAIN_JUNK_T;                                            // (stands in for the row above the lane's first row: see the scan)
+        cx.Iw = CHAIN_NONE;
         cx.dgm = 0; cx.pad = pad;
         cx.xw = xw_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];                 // the lane's first row is byte 3 of its top group
         cx.aw1 = (cx.xw >> 24) == q ? cx.MW1 : cx.XW1;
@@ -344,37 +360,50 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             tb_lane[(g) * 64] = tbw; }
         REP20(P1)
 #undef P1
-        // ---- insertion scan across the lanes (lane-tagged DPP prefix maximum; keys are relative to the contig) --------------------
-        // The lane's first row opens from the previous lane's last row, whose NEW S' word exists only now: the loop used the
-        // placeholder word 0 for it.  The true element has the same position and a score >= 0, so its key is >= the
-        // placeholder's; combined as the EARLIER element it replaces it (scan_combine keeps the earlier one on ties).
-        const int32_t nT = from_prev_lane((int)S[0], 0);                  // S' of the previous lane's last row (lane 0: row 0)
-        ScanEl run;
+        // ---- the insertion chain across the lanes ------------------------------------------------------------------------------------
+        // E = the chain of the lane's own openers as it arrives BEHIND the lane's last row (row_pass1's last step ended there; the
+        // first row's stand-in opener has long lost against real ones).  What arrives at lane l's first row is the best E of the
+        // lanes above — or the opener of row 0 (S' = 0: word GO1 at row 1) — carried down: score + ge per row, length + 1 per row.
+        // "Best" = largest score at a common position, earliest lane on ties (the extension wins ties, :321): a prefix maximum
+        // of position-normalised keys with the lane as a tag, as in fill_local16.hip.
+        int32_t Iin; uint32_t extin;
         {
-            ScanEl first; first.key = word_score(nT) + kfirst; first.q = (int32_t)word_len(nT) + qfirst;
-            ScanEl inc = scan_combine(first, cx.inc);
-            if (gl == 0) inc.key = SCAN_LOW;                              // lanes without rows
-            int32_t kt = (int32_t)(((uint32_t)inc.key << 6) | (uint32_t)(63 - lane));
+            const int32_t Eext = cx.Iw + GE1, Eopen = cx.Tup + GO1;         // one more step: from the lane's last row to the row behind it
+            const bool exitext = word_score(Eext) >= word_score(Eopen);
+            const int32_t E = exitext ? Eext : Eopen;
+            const int32_t pos_exit = pos_x + 1;                           // 1-based position of the row behind this lane's last row
+            int32_t nk = word_score(E) - ge * pos_exit;
+            if (gl == 0) nk = SCAN_LOW;                                   // lanes without rows
+            int32_t kt = (int32_t)(((uint32_t)nk << 6) | (uint32_t)(63 - lane));
             { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 1>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 2>(INT32_MIN, kt); kt = o > kt ? o : kt; }
             { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 4>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 8>(INT32_MIN, kt); kt = o > kt ? o : kt; }
             { const int32_t o = dpp_mov<DPP_BCAST15, 0xA>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_BCAST31, 0xC>(INT32_MIN, kt); kt = o > kt ? o : kt; }
             const int32_t rt = from_prev_lane(kt, INT32_MIN);             // exclusive: lanes before this one
-            run.key = rt >> 6;
-            run.q = __builtin_amdgcn_ds_bpermute((int)((63u - ((uint32_t)rt & 63u)) << 2), inc.q);
-            ScanEl seed; seed.key = SCAN_LOW; seed.q = 0;                 // I[curr][0] = MIN, length 0 (:192)
-            run = scan_combine(seed, run);
+            const uint32_t w = 63u - ((uint32_t)rt & 63u);                // the lane whose chain arrives (if any lane is above)
+            const int32_t Ew = __builtin_amdgcn_ds_bpermute((int)(w << 2), E);
+            const int32_t first_pos = pos_x + 1 - 4 * (int32_t)gl_x;      // 1-based position of this lane's first row
+            // the row-0 opener: word GO1 at position 1, key go + ge - ge; it is the earliest opener: it wins ties
+            const bool seed = lane == 0 || (kb0 - ge) >= (rt >> 6);
+            const uint32_t wn = w + 1u;                                   // the winner's exit position = first row of the lane after it
+            const int32_t w_exit = 4 * (int32_t)(wn * gq + (wn < grem ? wn : grem)) + 1;
+            const int32_t dist = seed ? first_pos - 1 : first_pos - w_exit;
+            const int32_t base = seed ? GO1 : Ew;
+            int32_t sc = word_score(base) + ge * dist; sc = sc > -28000 ? sc : -28000;      // (a chain that low loses to the first opener below)
+            Iin = word_make(sc, word_len(base) + (uint32_t)dist);
+            // did it arrive by an extension?  Not if it is the opener of the row right above: row 0 for lane 0, or the previous
+            // lane's last row when that lane's own last step chose the opener
+            const int32_t ext_prev = from_prev_lane(exitext ? 1 : 0, 0);
+            extin = (lane == 0) ? 0u : ((!seed && w + 1u == (uint32_t)lane && ext_prev == 0) ? 0u : (uint32_t)TBB_IEXT);
         }
 
         // ---- pass 2: the chain's extended bits, the insertion merge, the last column's int32 arrays; per group the lane's running
         // records, y-suffix records and the traceback dword ------------------------------------------------------------------------------
         Col2 c2;
-        c2.MW = MW; c2.XW = XW; c2.JSW = JSW; c2.ge = ge; c2.q = q; c2.kbase = kbase; c2.qbase = qbase; c2.bbase = bbase; c2.lbase = lbase;
-        c2.Tup = nT; c2.run = run; c2.rg4 = rg4_x;
-        c2.lastcol = (uint32_t)__builtin_amdgcn_readfirstlane(lastcol ? 1 : 0);        // (a scalar flag, not a lane mask)
-        c2.rS = __builtin_amdgcn_make_buffer_rsrc(V.S, 0, 0x7FFFFFFF, RSRC_WORD3);
-        c2.oSlen = (uint32_t)((const uint8_t*)V.Slen - (const uint8_t*)V.S); c2.oIval = (uint32_t)((const uint8_t*)V.Ival - (const uint8_t*)V.S); c2.oIlen = (uint32_t)((const uint8_t*)V.Ilen - (const uint8_t*)V.S);
-        const __amdgpu_buffer_rsrc_t rtb = __builtin_amdgcn_make_buffer_rsrc(V.tb + (size_t)(j - 1) * Rtot + roff, 0, 0x7FFFFFFF, RSRC_WORD3);
-        const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((uint8_t*)V.D + 8ull * roff, 0, 0x7FFFFFFF, RSRC_WORD3);
+        c2.MW = MW; c2.XW = XW; c2.JSW = JSW; c2.GE1 = GE1; c2.GO1 = GO1; c2.q = q;
+        c2.Iw = Iin; c2.extn = extin; c2.rg4 = rg4_x;
+        c2.lastcol = (uint32_t)__builtin_amdgcn_readfirstlane(lastcol ? 1 : 0);
+        c2.rS = rS; c2.oSlen = oSlen; c2.oIval = oIval; c2.oIlen = oIlen;
+        const __amdgpu_buffer_rsrc_t rtb = __builtin_amdgcn_make_buffer_rsrc(tb0 + (size_t)(j - 1) * Rtot, 0, 0x7FFFFFFF, RSRC_WORD3);
         Recs R; R.bw = 0; R.xrow = 0xFFFFFFFFu; R.r1 = 0xFFFFFFFFu; R.len1 = 0;
         const uint32_t ycol = n - j;
         uint32_t tbw0 = 0;                                               // group 0's traceback dword (row m's byte is in it)
@@ -450,7 +479,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                     if (lastcol) { const int32_t sn_ = word_score((int32_t)yrec[roff + yi].x); upd = Sm > sn_ || (Sm == sn_ && Slm > rl); }
                     if (upd) { u32x2 rec; rec.x = smw; rec.y = n - j; yrec[roff + yi] = rec; }
                 }
-                V.Lx[(size_t)c * (n + 1) + j] = lx;
+                Lx[(size_t)c * (n + 1) + j] = lx;
             }
             if (Sm > cb_.v) { cb_.v = Sm; cb_.row = m; cb_.len = Slm; }
             if (cb_.v > vrun) vrun = cb_.v;

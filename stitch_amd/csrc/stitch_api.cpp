@@ -382,7 +382,7 @@ bool local16_ok(const stitch_ctx& c, const Job& jb) {
 constexpr uint32_t REGS_WAVES = 4;
 uint32_t regs_plan(const stitch_ctx& c, const Job& jb) {
     if (c.knobs.no_regs || c.regs_wg_per_cu <= 0 || !local16_ok(c, jb) || c.opts.circular) return 0;
-    if (c.opts.gap_extend < -4096) return 0;
+    if (c.opts.gap_extend < -1024 || c.opts.gap_open + c.opts.gap_extend < -8000) return 0;      // (16-bit insertion-chain words, fill_regs.hip)
     uint64_t rows = 0;
     for (uint32_t a : jb.act) { if (c.al[a].m > fill_regs_rows_per_wave()) return 0; rows += c.al[a].m; }
     const uint64_t min_rows = c.knobs.regs_min_rows >= 0 ? (uint64_t)c.knobs.regs_min_rows : 2048u;
