@@ -118,8 +118,13 @@ __device__ __forceinline__ void row_pass2(uint32_t& Sreg, uint32_t& tbw, Col2& c
     constexpr int k = IDX & 3;
     const int32_t T = (int32_t)Sreg, Iw = c.Iw;
     tbw |= c.extn << (8 * k);
+    // the chain's step to the row below: it opens from S WITHOUT its own insertion candidate (dp_core.h, phase B), i.e. from T
+    // as pass 1 left it — taken first, so that the merge below can overwrite the row's register in place
+    const int32_t ext = Iw + c.GE1, open = T + c.GO1;
+    const bool isext = word_score(ext) >= word_score(open);
+    c.Iw = isext ? ext : open;
+    c.extn = isext ? (uint32_t)TBB_IEXT : 0u;                // "I extended" is a property of the NEXT row's cell
     // the insertion can only change the cell if its score reaches the cell's (T >= 0, so a negative insertion never does)
-    int32_t Tn = T;
     if (__builtin_expect(__ballot((Iw | 0xFFFF) >= T) != 0ull, 0)) {
         const int32_t bi = word_score(Iw); const uint32_t il = word_len(Iw);
         const uint32_t xb = (c.xw >> (8 * k)) & 0xFFu;
@@ -128,23 +133,17 @@ __device__ __forceinline__ void row_pass2(uint32_t& Sreg, uint32_t& tbw, Col2& c
         ra.JW = c.JSW + (xb == c.q ? c.MW : c.XW);
         ra.bs2h = (int32_t)(((uint32_t)bs_lane[IDX * 64] << 16) | 0xFFFFu);
         uint32_t mv;
-        Tn = row_phase_c_word(ra, bi, il, mv);
+        Sreg = (uint32_t)row_phase_c_word(ra, bi, il, mv);
         tbw = (tbw & ~(7u << (8 * k))) | (mv << (8 * k));
     }
     if (__builtin_expect(c.lastcol != 0u, 0)) {
         // column n: the int32 arrays the fix-up kernel reads (single_contig_aligner.rs:453-555)
         if (real) {
             const uint32_t vo = c.rg4 - 4u * IDX;
-            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score(Tn), c.rS, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len(Tn), c.rS, vo, c.oSlen, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score((int32_t)Sreg), c.rS, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len((int32_t)Sreg), c.rS, vo, c.oSlen, 0);
             __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score(Iw), c.rS, vo, c.oIval, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len(Iw), c.rS, vo, c.oIlen, 0);
         }
     }
-    Sreg = (uint32_t)Tn;
-    // the chain's step to the row below: it opens from S WITHOUT its own insertion candidate (dp_core.h, phase B) = T
-    const int32_t ext = Iw + c.GE1, open = T + c.GO1;
-    const bool isext = word_score(ext) >= word_score(open);
-    c.Iw = isext ? ext : open;
-    c.extn = isext ? (uint32_t)TBB_IEXT : 0u;
 }
 
 // the lane's running records over a contig's column (rows below m): the largest S word and the topmost row holding it (x-suffix
