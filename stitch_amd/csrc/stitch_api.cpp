@@ -75,6 +75,7 @@ struct Job {                                     // one full jump DP
 
 // Diagnostic / experiment knobs, read from the environment ONCE when a context is created (never per launch).
 struct Knobs {
+    bool fail_first_attempt = false;             // test hook: treat the first attempt of every cooperative launch as timed out
     bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false;
     size_t array_align = 0, job_align = 0;
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
@@ -83,6 +84,7 @@ struct Knobs {
         auto num = [](const char* name) -> unsigned long long { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : 0ull; };
         k.debug = getenv("STITCH_DEBUG") != nullptr; k.force_generic = getenv("STITCH_FORCE_GENERIC") != nullptr;
         k.profile_dump = getenv("STITCH_PROFILE_DUMP") != nullptr; k.banded_global = getenv("STITCH_BANDED_GLOBAL") != nullptr;
+        k.fail_first_attempt = getenv("STITCH_TEST_FAIL_FIRST_ATTEMPT") != nullptr;
         k.fill_only = getenv("STITCH_EXP_FILL_ONLY") != nullptr;      // experiment builds whose results are garbage: time the fill, skip the walk
         k.no_regs = getenv("STITCH_NO_REGS") != nullptr;             // keep the state-streaming kernel even where the register-resident one applies
         k.array_align = (size_t)num("STITCH_ARRAY_ALIGN"); k.job_align = (size_t)num("STITCH_JOB_ALIGN");
@@ -365,15 +367,31 @@ JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
 }
 
 // The Local-mode kernel keeps scores and alignment lengths in 16 bits (fill_local16.hip).
+// fill_local16.hip deals a read's active contigs round-robin to its G workgroups, and a workgroup's slot table holds
+// fill_local16_max_slots() 256-row tiles: the tiles of the fullest workgroup at G workgroups per read ...
+uint32_t local16_wg_tiles(const stitch_ctx& c, const Job& jb, uint32_t G) {
+    std::vector<uint32_t> per(G, 0);
+    for (size_t k = 0; k < jb.act.size(); ++k) per[k % G] += (c.al[jb.act[k]].m + 255) / 256;
+    return *std::max_element(per.begin(), per.end());
+}
+// ... and the fewest workgroups per read whose fullest one still fits its table (0: none up to 64 does)
+uint32_t local16_min_g(const stitch_ctx& c, const Job& jb) {
+    for (uint32_t G = 1; G <= 64 && G <= std::max<size_t>(1, jb.act.size()); ++G) if (local16_wg_tiles(c, jb, G) <= fill_local16_max_slots()) return G;
+    return 0;
+}
+
 bool local16_ok(const stitch_ctx& c, const Job& jb) {
     const stitch_opts& o = c.opts;
     if (c.knobs.force_generic) return false;
     const long long n = (long long)jb.y.size();
     const int32_t lo = std::min({o.mismatch_score, o.gap_open + o.gap_extend, o.jump_same, o.jump_opposite, o.jump_inter, o.match_score});
-    uint32_t tiles = 0; for (uint32_t a : jb.act) tiles += (c.al[a].m + 255) / 256;      // 256-row tiles when built with 4 rows per lane
-    if (tiles > 2048u * 16u) return false;                // the kernel's per-workgroup slot table (fill_local16.hip MAXSLOTS) at G <= 16
-    return o.mode == 0 && o.gap_open + o.gap_extend < 0 && (long long)std::max(o.match_score, 0) * n <= 32767 &&
-           n + (long long)c.max_m + 2 <= 65535 && lo >= -16000 && o.match_score <= 16000;
+    if (!(o.mode == 0 && o.gap_open + o.gap_extend < 0 && (long long)std::max(o.match_score, 0) * n <= 32767 &&
+          n + (long long)c.max_m + 2 <= 65535 && lo >= -16000 && o.match_score <= 16000)) return false;
+    // Alignment lengths are 16-bit too.  A chain's length = its read bases (<= n) + the contig bases it inserts; every inserted base
+    // costs |gap_extend| out of a score budget of match * n, so with gap_extend < 0 the length stays below n + match * n / |ge|;
+    // a free gap extension has no such bound.
+    if (o.gap_extend >= 0 || n + (long long)std::max(o.match_score, 0) * n / (long long)(-o.gap_extend) + 2 > 65535) return false;
+    return local16_min_g(c, jb) != 0;
 }
 
 // The register-resident Local-mode kernel (fill_regs.hip): one wave per active contig, REGS_WAVES waves per workgroup.  Returns the
@@ -518,7 +536,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         if (regs_G) max_jobs = std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs_wg_per_cu / regs_G);      // every workgroup of the launch resident at once
         else if (fast) {
             uint32_t tiles = 0; for (uint32_t a : jobs[k0].act) tiles += (c.al[a].m + 255) / 256;
-            g_min = std::max(1u, (tiles + 2047) / 2048);
+            g_min = local16_min_g(c, jobs[k0]);
             // at least 4 workgroups per read: measured best on cfg2 (64 reads x 4 beats 85 x 3 by 15 %: shorter columns per
             // workgroup, and 50 contigs still split evenly)
             // (reads aligned to a few contigs only -- pre-alignment subsets, origin re-alignments -- get fewer workgroups each,
@@ -532,7 +550,15 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         const size_t per_job = sizeof(JobView) + sizeof(WalkArgs) + 512;     // the launch's job table, after the jobs' own buffers
         while (k1 < jobs.size() && used + lay[k1].stride + per_job + view_room <= c.arena_bytes && (k1 - k0) < max_jobs &&
-               (k1 == k0 || regs_plan(c, jobs[k1]) == regs_G || !fast)) { used += lay[k1].stride + per_job; ++k1; }
+               (k1 == k0 || regs_plan(c, jobs[k1]) == regs_G || !fast)) {
+            if (fast && !regs_G && k1 > k0) {
+                // a later job may need MORE workgroups than the first (shorter read, more contigs): all workgroups of the launch
+                // must still be resident at once
+                const uint32_t gk = local16_min_g(c, jobs[k1]);
+                if (gk > g_min) { if ((k1 - k0 + 1) * (size_t)gk > (size_t)c.n_cus) break; g_min = gk; max_jobs = std::min(max_jobs, std::max<size_t>(1, (size_t)c.n_cus / gk)); }
+            }
+            used += lay[k1].stride + per_job; ++k1;
+        }
         if (k1 == k0) return fail(STITCH_ENOMEM, "arena too small for one job");
         const uint32_t nj = (uint32_t)(k1 - k0);
         std::vector<JobView> views(nj); std::vector<WalkArgs> wargs(nj);
@@ -621,6 +647,13 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             if (c.knobs.wg_per_read) G = (uint32_t)c.knobs.wg_per_read;
             G = std::max(G, g_min);
             if (nj * G > cus) G = std::max(1u, cus / nj);
+            // the slot table of the fullest workgroup must hold its tiles (round-robin dealing is not monotone in G)
+            for (;;) {
+                uint32_t worst = 0; for (uint32_t q = 0; q < nj; ++q) worst = std::max(worst, local16_wg_tiles(c, jobs[k0 + q], G));
+                if (worst <= fill_local16_max_slots()) break;
+                if ((G + 1) * nj > cus) return fail(STITCH_EINTERNAL, "no workgroup count fits the Local-mode kernel's slot table for this launch");
+                ++G;
+            }
             // the waves of a workgroup share its tiles evenly (fill_local16.hip), so use all 12 unless there are fewer tiles
             uint32_t min_tiles = 0xFFFFFFFFu;
             for (uint32_t q = 0; q < nj; ++q) { uint32_t t = 0; for (uint32_t a : jobs[k0 + q].act) t += (c.al[a].m + 255) / 256; min_tiles = std::min(min_tiles, t / G); }
@@ -638,8 +671,14 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             for (size_t k = 0; k < act.size(); ++k) per[k % G] += (c.al[act[k]].m + 255) / 256;
             for (uint32_t v : per) slots_cap = std::max(slots_cap, v);
         }
-        if (regs_G) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, nj, G, REGS_WAVES, mx, sh, c.stream); }
-        else if (fast) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, c.stream);
+        // The kernels whose workgroups wait for each other (several workgroups per read) need every workgroup of the launch resident
+        // at once.  The grid is sized for that, but another process on the device, CU masking or reserved CUs can break it: the
+        // kernels then give up after a bounded wait (error word 1) and the launch is run ONCE more on the streaming kernel with one
+        // workgroup per read (nothing waits across workgroups there), or on the generic kernel if a read's tiles exceed one slot table.
+        uint32_t kind = regs_G ? 2u : fast ? 1u : 0u;
+        for (int attempt = 0;; ++attempt) {
+        if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, nj, G, REGS_WAVES, mx, sh, c.stream); }
+        else if (kind == 1u) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, c.stream);
         else launch_fill(d_views, nj, waves, sh, c.stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev[1], c.stream));
@@ -648,7 +687,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             HIP_TRY(hipStreamSynchronize(c.stream));
             float ms_f = 0; HIP_TRY(hipEventElapsedTime(&ms_f, c.ev[0], c.ev[1])); c.tm.fill_ms += ms_f; c.tm.launches += 1; c.tm.jobs += nj;
             if (c.knobs.debug) fprintf(stderr, "[stitch] fill-only launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms\n", nj, G, waves, ms_f);
-            k0 = k1; continue;
+            break;
         }
         uint32_t max_nact_mode1 = 0;
         for (uint32_t q = 0; q < nj; ++q) if (jobs[k0 + q].mode == 1) max_nact_mode1 = std::max(max_nact_mode1, lay[k0 + q].nact);
@@ -661,7 +700,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         HIP_TRY(hipEventElapsedTime(&ms_fill, c.ev[0], c.ev[1])); c.tm.fill_ms += ms_fill;
         HIP_TRY(hipEventElapsedTime(&ms, c.ev[1], c.ev[2])); c.tm.walk_ms += ms;
         if (c.knobs.debug) fprintf(stderr, "[stitch] launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms, fix-up + walk %.1f ms\n", nj, G, waves, ms_fill, ms);
-        c.tm.launches += 1; c.tm.jobs += nj;
+        if (attempt == 0) { c.tm.launches += 1; c.tm.jobs += nj; }
         if (c.knobs.profile_dump && fast) {
             unsigned long long pf[128]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[0].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
             unsigned long long t_first = ~0ull;
@@ -681,12 +720,34 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             static const char* nm[8] = {"gather/loop", "select", "barrier1", "slot-setup", "tile", "finalize", "tile_wait", "barrier2"};
             for (int w = 0; w < waves; ++w) { fprintf(stderr, "[prof] wave %d:", w); for (int k = 0; k < 8; ++k) { if (k == 2) fprintf(stderr, " tiles=%llu merged=%llu", pf[w * 8 + 2] >> 32, pf[w * 8 + 2] & 0xFFFFFFFFull); else if (k == 1) fprintf(stderr, " simd=%u slot=%u cu=%u", (unsigned)((pf[w * 8 + 1] >> 4) & 3), (unsigned)(pf[w * 8 + 1] & 15), (unsigned)((pf[w * 8 + 1] >> 8) & 15)); else fprintf(stderr, " %s=%.1fM", nm[k], pf[w * 8 + k] / 1e6); } fprintf(stderr, "\n"); }
         }
-        if (fast) for (uint32_t q = 0; q < nj; ++q) {
+        bool timed_out = false;
+        if (kind != 0u) for (uint32_t q = 0; q < nj; ++q) {
             uint32_t e = 0; HIP_TRY(hipMemcpy(&e, views[q].err, 4, hipMemcpyDeviceToHost));
             if ((e & 0xFFu) == 2u) return fail(STITCH_EINTERNAL, "fill kernel bounds check failed, code " + std::to_string(e >> 8));
-            if (e) return fail(STITCH_EINTERNAL, "the fill kernel timed out waiting for a partner (workgroups of one read not co-resident, or a lost hand-off between waves)");
+            if (e) timed_out = true;
+        }
+        if (attempt == 0 && c.knobs.fail_first_attempt && (kind == 2u || G > 1)) timed_out = true;      // (test hook: exercises the relaunch)
+        if (!timed_out) break;
+        if (attempt > 0 || (kind == 1u && G == 1)) return fail(STITCH_EINTERNAL, "the fill kernel timed out waiting for a partner (workgroups of one read not co-resident, or a lost hand-off between waves)");
+        {
+            bool one_table = true;
+            for (uint32_t q = 0; q < nj; ++q) if (local16_wg_tiles(c, jobs[k0 + q], 1) > fill_local16_max_slots()) one_table = false;
+            kind = one_table ? 1u : 0u; G = 1; slots_cap = 0;
+            for (uint32_t q = 0; q < nj; ++q) {
+                slots_cap = std::max(slots_cap, local16_wg_tiles(c, jobs[k0 + q], 1));
+                views[q].tb_keyfmt = kind; waves = std::max(waves, pick_waves(c, lay[k0 + q].nact, MAX_WAVES_GENERIC));
+                HIP_TRY(hipMemsetAsync(c.arena + base[q] + lay[k0 + q].off_xchg, 0, 32ull * c.C + 4096, c.stream));
+            }
+            if (kind == 1u) waves = MAX_WAVES_LOCAL;
+            HIP_TRY(hipMemcpyAsync(d_views, views.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, c.stream));
+            c.tm.fill_kind = kind; c.tm.wg_per_read = 1; c.tm.fallbacks += 1;
+            if (c.knobs.debug) fprintf(stderr, "[stitch] partner timeout: launch of %u jobs repeated with one workgroup per read (kernel kind %u)\n", nj, kind);
+            HIP_TRY(hipEventRecord(c.ev[0], c.stream));
+        }
         }
 
+
+        if (c.knobs.fill_only) { k0 = k1; continue; }
         // download chains: headers first, then the operation lists, both batched through a pinned staging buffer (one
         // synchronous pageable copy per chain costs ~0.15 ms each; --suboptimal yields hundreds of chains per read)
         auto t_d2h0 = std::chrono::steady_clock::now();
@@ -827,7 +888,9 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         {
             const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({nj, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16}));
             std::atomic<size_t> next{0};
+            std::atomic<bool> failed{false};
             auto work = [&]() {
+                try {
                 std::vector<uint16_t> lo_, hi_; std::vector<std::vector<Seed>> seeds_;
                 for (;;) {
                     const size_t q = next.fetch_add(1); if (q >= nj) break;
@@ -848,9 +911,13 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
                         memcpy(bands + P.band_off + A.m + 1, hi_.data(), sizeof(uint16_t) * (A.m + 1));
                     }
                 }
+                } catch (...) { failed.store(true); next.store(nj); }      // (out of host memory in a worker: reported by the caller, never std::terminate)
             };
-            std::vector<std::thread> pool; for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
-            work(); for (auto& th : pool) th.join();
+            struct Joiner { std::vector<std::thread> pool; ~Joiner() { for (auto& th : pool) if (th.joinable()) th.join(); } } J;
+            for (unsigned t = 1; t < nt; ++t) J.pool.emplace_back(work);
+            work();
+            for (auto& th : J.pool) th.join();
+            if (failed.load()) throw std::bad_alloc();
         }
         for (size_t k = 0; k < np; ++k) {
             if (full[k] == 1) { S.full_ids.push_back((uint32_t)k); S.full_max_m = std::max(S.full_max_m, S.pairs[k].m); }

@@ -89,3 +89,15 @@ def test_long_contigs_near_the_register_capacity():
     reads = [P.chimera(rng, targets, rng.randint(150, 400), both=True) for _ in range(6)]
     P.run_pair(targets, reads, double_strand=True)
     P.run_pair(targets, reads[:3], suboptimal=True, check_sam=False)
+
+
+def test_partner_timeout_falls_back_to_one_workgroup_per_read(monkeypatch):
+    """a launch whose workgroups cannot all be resident ends with a bounded wait; the host repeats it once with one workgroup
+    per read instead of failing the batch (test hook: the first attempt of every cooperative launch counts as timed out)"""
+    monkeypatch.setenv("STITCH_TEST_FAIL_FIRST_ATTEMPT", "1")
+    db = synth.make_db(6, 900, 4)
+    targets = [(n, s.decode()) for n, s in db]
+    reads = [r.decode() for r in synth.make_reads(db, 8, 400, 6, both_strands=True)]
+    al = P.run_pair(targets, reads, double_strand=True)
+    tm = al.timing()
+    assert tm["fallbacks"] >= 1 and tm["fill_kind"] == 1 and tm["wg_per_read"] == 1
