@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--contig-len", type=int, default=5000)
     ap.add_argument("--cpu-reads", type=int, default=-1, help="reads in the cpu_baseline sample (-1 = one per worker thread, 0 = skip)")
     ap.add_argument("--cpu-prefix", type=int, default=2500, help="bases of each sample read the CPU aligns (0 = whole read: 40 GB and minutes per read)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="worker threads of the CPU leg (0 = min(cores, free RAM / RAM per worker, 8))")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="worker threads of the CPU leg (0 = min(cores, free RAM / RAM per worker, 4))")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -231,8 +231,9 @@ def cpu_leg(args, db, stream, aligners):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     free = host_memory_available()
     # (more workers do not help: the reference's 16-byte row-major cells make every cell a cache and TLB miss, and 16 workers
-    # aligned 38 Mcells/s together where one aligns 25 on the same host — measured; eight keep the leg near a minute)
-    T = args.cpu_threads if args.cpu_threads > 0 else max(1, min(cores, int(free * 0.6 // max(1, ram_per_worker)), 8))
+    # aligned 38 Mcells/s together and 8 workers 26 where one aligns 25 on the same host — measured; four keep the leg
+    # under two minutes)
+    T = args.cpu_threads if args.cpu_threads > 0 else max(1, min(cores, int(free * 0.6 // max(1, ram_per_worker)), 4))
     n_sample = args.cpu_reads if args.cpu_reads > 0 else T
     # distinct reads (a duplicated neighbour is the same job for both sides), each cut to the stated prefix
     sample = []

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the numbers profiles/ holds, on a GPU box (run from the repository root):
 #   bash profiles/collect.sh r01_g
-# 1. bench.py as the driver runs it            -> profiles/<tag>_bench_local16.json
-# 2. rocprofv3 --kernel-trace --stats of that   -> profiles/<tag>_kernel_stats_local16.csv
+# 1. bench.py as the driver runs it            -> profiles/<tag>_bench_fill.json
+# 2. rocprofv3 --kernel-trace --stats of that   -> profiles/<tag>_kernel_stats_fill.csv
 # 3. PMC counters, one pass per group (TCC FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md), never
-#    combined with a trace domain                                                        -> profiles/<tag>_pmc_local16.json
+#    combined with a trace domain                                                        -> profiles/<tag>_pmc_fill.json
 # The program follows `--` directly (no env/bash wrapper: the profiler has initialised the GPU by then).
 set -o pipefail
 tag=${1:-r01_x}
@@ -20,5 +20,5 @@ done
 python3 profiles/summarize.py "$out" "$tag"
 # the bench line last: its roofline.traffic / roofline.valu figures read the PMC summary just written
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; exit 1; }
-cp "$out/bench.json" "profiles/${tag}_bench_local16.json"
+cp "$out/bench.json" "profiles/${tag}_bench_fill.json"
 cp profiles/${tag}_* "$out/"        # gpurun merges only gpurun_out/ back: copy from there into profiles/ and commit

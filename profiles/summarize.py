@@ -1,7 +1,8 @@
 """Turns the rocprofv3 output of profiles/collect.sh into the two committed summaries:
-<tag>_kernel_stats_local16.csv (per-kernel calls / total / average duration) and <tag>_pmc_local16.json (per kernel and
+<tag>_kernel_stats_fill.csv (per-kernel calls / total / average duration) and <tag>_pmc_fill.json (per kernel and
 counter: launches seen and the raw per-launch average, summed over the counter's instances)."""
 import csv
+import re
 import glob
 import json
 import os
@@ -16,7 +17,7 @@ from bench import kernel_src_hash          # the hash bench.py compares before i
 stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
-    with open(os.path.join(here, f"{tag}_kernel_stats_local16.csv"), "w") as f:
+    with open(os.path.join(here, f"{tag}_kernel_stats_fill.csv"), "w") as f:
         f.write("Name,Calls,TotalDurationUs,AverageUs,Percentage\n")
         for r in rows:
             f.write(f"\"{r['Name']}\",{r['Calls']},{float(r['TotalDurationNs']) / 1e3:.3f},{float(r['AverageNs']) / 1e3:.3f},{r['Percentage']}\n")
@@ -26,7 +27,7 @@ for path in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"
     for r in csv.DictReader(open(path)):
         if "stitch::" not in r["Kernel_Name"]:
             continue
-        name = r["Kernel_Name"].split("(")[0]
+        name = re.sub(r"<.*", "", re.sub(r"^void\s+", "", r["Kernel_Name"].split("(")[0]))      # "void stitch::fill_regs_kernel<1>(...)" -> "stitch::fill_regs_kernel"
         pmc[name][r["Counter_Name"]][(path, r["Dispatch_Id"])] += float(r["Counter_Value"])
 summary = {k: {c: {"launches": len(d), "avg_per_launch_raw": sum(d.values()) / len(d)} for c, d in sorted(cs.items())} for k, cs in pmc.items()}
 cells = None
@@ -38,6 +39,6 @@ if summary:
     summary["cells_per_launch"] = cells
     summary["kernel_src_sha"] = kernel_src_hash()
     summary["units"] = "FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them (FETCH_SIZE counts half of a wide read on gfx950)"
-    with open(os.path.join(here, f"{tag}_pmc_local16.json"), "w") as f:
+    with open(os.path.join(here, f"{tag}_pmc_fill.json"), "w") as f:
         json.dump(summary, f, indent=1)
 print("kernel stats:", bool(stats), "pmc kernels:", list(summary))
