@@ -288,7 +288,7 @@ def cpu_bench_sam(targets, reads, threads=1, name_base=0, **opts):
     rb = (C.c_uint8 * max(1, len(cat))).from_buffer_copy(cat or b"\0")
     cells = C.c_uint64(0)
     scores = np.zeros(len(reads), dtype=np.int64)
-    cap = 64 * 1024 * max(1, len(reads)) + 8 * len(cat)
+    cap = (4 << 20) * max(1, len(reads)) + 64 * len(cat)          # (a chimeric read yields a record per segment, each with SEQ, QUAL and SA)
     buf = C.create_string_buffer(cap)
     soffs = np.zeros(len(reads) + 1, dtype=np.uint64)
     secs = lib().orc_bench_sam(o, f, C.c_size_t(len(targets)), names, seqs, lens, rb,

@@ -61,7 +61,7 @@ struct Col {
     int32_t MW1, XW1, GE1, GO1, JSWm1;         // (match, mismatch) << 16 | 1; gap words; the column's jump word minus one length unit
     uint32_t q;                                // y[j-1]
     int32_t aw1, DG;                           // the current row's (match | mismatch) word and diagonal candidate: old S word of the row above + aw1
-    uint32_t xw;                               // four bases: the group of the NEXT row
+    uint32_t xw, xwn;                          // four bases: the group of the NEXT row; the group below it (read from LDS a group ahead)
     int32_t Tup;                               // new S' word of the row above
     int32_t Iw;                                // insertion chain of the lane's own openers, arriving at the current row
     int32_t dgm; uint32_t pad;                 // row m (register `pad` of its lane): its diagonal candidate, needed for its finalisation
@@ -77,7 +77,8 @@ __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32
     if (IDX > 0) {
         // the NEXT row's diagonal candidate takes this row's old S word: computed here, so that the old word is dead before the
         // new one is written and the row's S register is updated in place
-        if (k == 0) c.xw = xw_lane[((IDX > 0 ? IDX - 1 : 0) >> 2) * 64];
+        if (k == 0) c.xw = c.xwn;                            // (read while the group above was computed: no LDS latency here)
+        if (k == 3 && IDX >= 7) c.xwn = xw_lane[((IDX >= 7 ? IDX - 7 : 0) >> 2) * 64];
         const uint32_t xbn = (c.xw >> (8 * (k == 0 ? 3 : k - 1))) & 0xFFu;
         c.aw1 = xbn == c.q ? c.MW1 : c.XW1;
         c.DG = Sold + c.aw1;                                 // diagonal: score + a, length + 1
@@ -92,7 +93,7 @@ __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32
     const bool c3 = JW > X;
     int32_t T = c3 ? JW : bs2;
     const bool c4 = T < 0;                                   // x-prefix clip: score 0, length 0
-    T = c4 ? 0 : T;
+    T = T > 0 ? T : 0;
     const uint32_t code = (c4 ? MK_XPRE : c3 ? MK_JUMP : c1 ? MK_DEL : MK_DIAG) | (dext ? (uint32_t)TBB_DEXT : 0u);
     tbw = k == 3 ? code : ((tbw << 8) | code);               // byte k of the group's dword: register 4g+3 first, 4g last
     bs_lane[IDX * 64] = (uint16_t)((uint32_t)bs2 >> 16);
@@ -104,7 +105,7 @@ __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32
 
 struct Col2 {
     int32_t MW, XW, JSW, GE1, GO1; uint32_t q;
-    uint32_t xw;
+    uint32_t tbn;                              // the traceback codes of the NEXT group (read from LDS a group ahead)
     int32_t Iw;                                // the insertion chain's word AT the current row ...
     uint32_t extn;                             // ... and TBB_IEXT if it got there by an extension (else 0)
     uint32_t lastcol; uint32_t rg4;            // j == n; 4 x (index of register 0's row in the job's linear row arrays)
@@ -114,7 +115,7 @@ struct Col2 {
 // ---- pass 2, one row: the merge of the insertion into the cell where it changes it (dp_core.h row_phase_c_word: beats
 // best{diagonal, deletion}, is not beaten by the jump), the chain's "extended" bit, and the chain's step to the next row
 template <int IDX>
-__device__ __forceinline__ void row_pass2(uint32_t& Sreg, uint32_t& tbw, Col2& c, const uint16_t* bs_lane, const bool real) {
+__device__ __forceinline__ void row_pass2(uint32_t& Sreg, uint32_t& tbw, Col2& c, const uint32_t* xw_lane, const uint16_t* bs_lane, const bool real) {
     constexpr int k = IDX & 3;
     const int32_t T = (int32_t)Sreg, Iw = c.Iw;
     tbw |= c.extn << (8 * k);
@@ -125,9 +126,9 @@ __device__ __forceinline__ void row_pass2(uint32_t& Sreg, uint32_t& tbw, Col2& c
     c.Iw = isext ? ext : open;
     c.extn = isext ? (uint32_t)TBB_IEXT : 0u;                // "I extended" is a property of the NEXT row's cell
     // the insertion can only change the cell if its score reaches the cell's (T >= 0, so a negative insertion never does)
-    if (__builtin_expect(__ballot((Iw | 0xFFFF) >= T) != 0ull, 0)) {
+    if (__builtin_expect(__ballot(word_score(Iw) >= word_score(T)) != 0ull, 0)) {
         const int32_t bi = word_score(Iw); const uint32_t il = word_len(Iw);
-        const uint32_t xb = (c.xw >> (8 * k)) & 0xFFu;
+        const uint32_t xb = (xw_lane[(IDX >> 2) * 64] >> (8 * k)) & 0xFFu;
         RowW ra;
         ra.T = T; ra.mvT = (tbw >> (8 * k)) & 7u;
         ra.JW = c.JSW + (xb == c.q ? c.MW : c.XW);
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         cx.Iw = CHAIN_NONE;
         cx.dgm = 0; cx.pad = pad;
         cx.xw = xw_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];                 // the lane's first row is byte 3 of its top group
+        cx.xwn = xw_lane[(gl_x > 1 ? gl_x - 2 : 0) * 64];                // ... and the group below it
         cx.aw1 = (cx.xw >> 24) == q ? cx.MW1 : cx.XW1;
         // the row above a lane's first row is the previous lane's last row: register 0; row 0 for lane 0 (score 0, length 0 in Local mode)
         cx.DG = from_prev_lane((int)S[0], 0) + cx.aw1;
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         Col2 c2;
         c2.MW = MW; c2.XW = XW; c2.JSW = JSW; c2.GE1 = GE1; c2.GO1 = GO1; c2.q = q;
         c2.Iw = Iin; c2.extn = extin; c2.rg4 = rg4_x;
+        c2.tbn = tb_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];
         c2.lastcol = (uint32_t)__builtin_amdgcn_readfirstlane(lastcol ? 1 : 0);
         c2.rS = rS; c2.oSlen = oSlen; c2.oIval = oIval; c2.oIlen = oIlen;
         const __amdgpu_buffer_rsrc_t rtb = __builtin_amdgcn_make_buffer_rsrc(tb0 + (size_t)(j - 1) * Rtot, 0, 0x7FFFFFFF, RSRC_WORD3);
@@ -410,9 +413,9 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         // register k of group 0 holds a row below m (a row that takes part in the records) unless this is the lane of row m and
         // k <= pad (k < pad: no row at all; k == pad: row m itself)
 #define P2(g) if ((uint32_t)(g) < gl_x) { \
-            uint32_t tbw = tb_lane[(g) * 64]; c2.xw = xw_lane[(g) * 64]; \
-            row_pass2<4 * (g) + 3>(S[4 * (g) + 3], tbw, c2, bs_lane, !((g) == 0 && mine && 3u < pad)); row_pass2<4 * (g) + 2>(S[4 * (g) + 2], tbw, c2, bs_lane, !((g) == 0 && mine && 2u < pad)); \
-            row_pass2<4 * (g) + 1>(S[4 * (g) + 1], tbw, c2, bs_lane, !((g) == 0 && mine && 1u < pad)); row_pass2<4 * (g)>(S[4 * (g)], tbw, c2, bs_lane, !((g) == 0 && mine && 0u < pad)); \
+            uint32_t tbw = c2.tbn; if ((g) > 0) c2.tbn = tb_lane[((g) > 0 ? (g) - 1 : 0) * 64]; \
+            row_pass2<4 * (g) + 3>(S[4 * (g) + 3], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 3u < pad)); row_pass2<4 * (g) + 2>(S[4 * (g) + 2], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 2u < pad)); \
+            row_pass2<4 * (g) + 1>(S[4 * (g) + 1], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 1u < pad)); row_pass2<4 * (g)>(S[4 * (g)], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 0u < pad)); \
             const uint32_t t3 = ((g) == 0 && mine && 3u <= pad) ? 0u : S[4 * (g) + 3], t2 = ((g) == 0 && mine && 2u <= pad) ? 0u : S[4 * (g) + 2]; \
             const uint32_t t1 = ((g) == 0 && mine && 1u <= pad) ? 0u : S[4 * (g) + 1], t0 = ((g) == 0 && mine) ? 0u : S[4 * (g)]; \
             group_records(R, t3, t2, t1, t0, rowbase + (nrows - 4u - 4u * (g))); \
