@@ -110,6 +110,22 @@ int stitch_last_timing(const stitch_ctx*, stitch_timing* out);
 int stitch_prealign_band(const uint8_t* read, uint32_t read_len, const uint8_t* target, uint32_t target_len, uint32_t k, uint32_t w,
                          int32_t match, int32_t gap_open, int32_t gap_extend, uint16_t* lo, uint16_t* hi);
 
+/* Multi-GPU sharding of a read stream (host only): the contiguous block [*lo, *hi) of the batch for `rank` of `world` ranks.
+ * Blocks are equal shares cut only where two consecutive reads differ, so a run of identical reads — which the reference
+ * aligns once (FastxGroupingIterator, align/io.rs:118-146) — stays on one rank; concatenated in rank order the blocks are the
+ * stream, so per-rank outputs concatenated in rank order equal the single-GPU output (fg-stitch-cli/src/commands/align.rs:
+ * 338-441 keeps input order through its channels).  Reads are compared as given (case-sensitively, like the reference). */
+int stitch_shard_range(const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads, uint32_t world, uint32_t rank,
+                       uint32_t* lo, uint32_t* hi);
+
+/* Test hook (host only, no device needed): the library's Alignment::split_at_y (align/alignment.rs:207-360; used by
+ * realign_origin to un-rotate a re-aligned read) on a caller-supplied chain.  `mode` is the alignment's own mode (0 local,
+ * 1 query-local, 2 target-local, 3 global, 4 custom = what the traceback produces).  Writes the result chain and at most `cap`
+ * operations; returns the number of operations of the result (nothing is written beyond cap) or a negative error.
+ * tests/test_split_at_y_golden.py runs the reference's own test vectors through it. */
+long stitch_split_at_y(const stitch_chain* in, const stitch_op* in_ops, int32_t mode, uint32_t y_pivot,
+                       stitch_chain* out, stitch_op* out_ops, uint32_t cap);
+
 const char* stitch_last_error(void);
 const char* stitch_version(void);
 

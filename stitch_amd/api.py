@@ -59,7 +59,7 @@ class _Timing(C.Structure):  # == stitch_timing
 
 EXPORTS = ("stitch_opts_default", "stitch_index_build", "stitch_index_serialize", "stitch_index_deserialize",
            "stitch_index_n_contigs", "stitch_index_destroy", "stitch_ctx_create", "stitch_ctx_destroy", "stitch_align_batch",
-           "stitch_format_sam", "stitch_last_timing", "stitch_prealign_band", "stitch_last_error", "stitch_version")
+           "stitch_format_sam", "stitch_last_timing", "stitch_prealign_band", "stitch_split_at_y", "stitch_shard_range", "stitch_last_error", "stitch_version")
 
 _lib = None
 
@@ -75,6 +75,7 @@ def lib():
         L.stitch_last_error.restype = C.c_char_p
         L.stitch_version.restype = C.c_char_p
         L.stitch_format_sam.restype = C.c_long
+        L.stitch_split_at_y.restype = C.c_long
         L.stitch_index_n_contigs.restype = C.c_uint32
         _lib = L
     return _lib
@@ -145,6 +146,29 @@ class Alignment:
     def __repr__(self):
         return (f"contig-idx: {self.start_contig_idx}-{self.end_contig_idx} x-span: {self.xstart}-{self.xend}/{self.xlen} "
                 f"y-span: {self.ystart}-{self.yend}/{self.ylen} score: {self.score} cigar: {self.cigar()} aln-len: {self.length}")
+
+
+def split_at_y(aln, mode, y_pivot):
+    """Alignment::split_at_y (alignment.rs:207-360) as the library implements it (host code; no device needed)."""
+    ops = (_Op * max(1, len(aln.operations)))()
+    for k, (kind, a, b) in enumerate(aln.operations):
+        ops[k].kind = kind
+        ops[k].contig = a if kind == 6 else 0
+        ops[k].arg = b if kind == 6 else a
+    c = _Chain()
+    for f in Alignment.__slots__[:-1]:
+        setattr(c, f, getattr(aln, f))
+    c.ops_len = len(aln.operations)
+    out, cap = _Chain(), 2 * len(aln.operations) + 16
+    out_ops = (_Op * cap)()
+    n = lib().stitch_split_at_y(C.byref(c), ops, int(MODES[mode]) if isinstance(mode, str) else int(mode), C.c_uint32(y_pivot), C.byref(out), out_ops, C.c_uint32(cap))
+    if n < 0 or n > cap:
+        raise StitchError(lib().stitch_last_error().decode())
+    r = Alignment()
+    for f in Alignment.__slots__[:-1]:
+        setattr(r, f, int(getattr(out, f)))
+    r.operations = [(int(o.kind), int(o.contig), int(o.arg)) if o.kind == 6 else (int(o.kind), int(o.arg) if o.kind in (4, 5, 7) else 0, 0) for o in out_ops[:n]]
+    return r
 
 
 class Builder:

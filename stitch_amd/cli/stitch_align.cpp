@@ -6,10 +6,17 @@
 //   per read          -> stitch_format_sam             (aligners/mod.rs:622-973)
 //   header            -> @HD, @SQ per target, @PG      (align.rs:393-416)
 //
+// `--devices 0,1,...` runs one worker PROCESS per GPU (the counterpart of the reference's worker threads, align.rs:345-390): the
+// parent — which never touches a GPU — builds the reference index once and hands it to the workers as the serialized blob,
+// cuts the read stream into contiguous blocks at read-group boundaries (stitch_shard_range), starts the workers (fork + exec of
+// this program, before any GPU call) and concatenates their records in rank order behind the header: byte for byte what one
+// device writes.
 // The alignment itself only exists on the GPU: without a device the program stops with the library's error.
 // `--dry-run` parses the inputs and writes the header only (no device needed); `--convert-sam FILE` re-encodes a SAM
 // file as BAM (what `--output-format bam` does to the records it produces) so that the encoder can be tested alone.
 #include <signal.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cstdint>
@@ -178,6 +185,10 @@ struct Args {
     std::string reads_fastq, reads_fasta, ref_fasta, out_format = "sam", convert_sam;
     stitch_opts o; int jump_score = -10; bool js_same = false, js_opp = false, js_inter = false;
     int threads = 2, compression = 0, device = 0; uint32_t batch = 1024; bool decompress = false, dry_run = false;
+    std::vector<int> devices;                       // --devices: one worker process per entry
+    // worker mode (set by the parent of a --devices run): records [shard_lo, shard_hi) only, SAM records without header to
+    // shard_out, the reference index from the serialized blob
+    long shard_lo = -1, shard_hi = -1; std::string shard_out, index_blob;
 };
 
 const char* USAGE =
@@ -201,6 +212,8 @@ const char* USAGE =
     "  -c, --compression N         BGZF level of the BAM output (0)\n"
     "      --output-format FMT     sam (default) | bam\n"
     "      --device N  --batch N   GPU ordinal (0), reads per library call (1024)\n"
+    "      --devices A,B,...       one worker process per listed GPU; reads are cut into contiguous blocks at read-group\n"
+    "                              boundaries, the output is the single-device output (a read FILE is needed, not stdin)\n"
     "      --dry-run               parse the inputs, write the header, align nothing (no GPU needed)\n";
 
 bool parse_bool(const std::string& v, bool& out) {
@@ -260,6 +273,10 @@ Args parse(int argc, char** argv) {
         else if (k == "-c" || k == "--compression") a.compression = num(i);
         else if (k == "--output-format") a.out_format = lower(need(i));
         else if (k == "--device") a.device = num(i);
+        else if (k == "--devices") { const std::string v = need(i); size_t p = 0; while (p <= v.size()) { size_t e = v.find(',', p); if (e == std::string::npos) e = v.size(); if (e > p) a.devices.push_back(atoi(v.substr(p, e - p).c_str())); p = e + 1; } if (a.devices.empty()) die("--devices needs a list of GPU ordinals"); }
+        else if (k == "--shard") { a.shard_lo = num(i); a.shard_hi = num(i); }
+        else if (k == "--shard-out") a.shard_out = need(i);
+        else if (k == "--index-blob") a.index_blob = need(i);
         else if (k == "--batch") a.batch = (uint32_t)std::max(1, num(i));
         else if (k == "--dry-run") a.dry_run = true;
         else if (k == "--convert-sam") a.convert_sam = need(i);
@@ -314,8 +331,9 @@ int main(int argc, char** argv) {
     { FastxReader fr(a.ref_fasta, false); Rec r; while (fr.next(r)) { const std::string nm = first_word(r.head); if (nm.empty()) die("empty read name"); names.push_back(nm); seqs.push_back(r.seq); } }
     if (names.empty()) die("Found no sequences in the FASTA");
     for (size_t k = 0; k < names.size(); ++k) { enc.ref_id[names[k]] = (int)k; enc.refs.push_back({names[k], (uint32_t)seqs[k].size()}); }
+    const bool worker = a.shard_lo >= 0;
     const std::string header = sam_header(enc.refs, argc, argv);
-    if (out.bam) enc.header(out, header); else out.put(header.data(), header.size());
+    if (!worker) { if (out.bam) enc.header(out, header); else out.put(header.data(), header.size()); }
 
     const bool fastq = !a.reads_fastq.empty();
     FastxReader reads(fastq ? a.reads_fastq : a.reads_fasta, fastq);
@@ -324,7 +342,52 @@ int main(int argc, char** argv) {
     std::vector<const char*> cn; std::vector<const uint8_t*> cs; std::vector<uint32_t> cl;
     for (size_t k = 0; k < names.size(); ++k) { cn.push_back(names[k].c_str()); cs.push_back((const uint8_t*)seqs[k].data()); cl.push_back((uint32_t)seqs[k].size()); }
     stitch_index* index = nullptr;
-    if (stitch_index_build(cn.data(), cs.data(), cl.data(), (uint32_t)names.size(), &index) != STITCH_OK) die(stitch_last_error());
+    if (!a.index_blob.empty()) {                        // worker: the index the parent built, as the serialized blob
+        FILE* f = fopen(a.index_blob.c_str(), "rb"); if (!f) die("cannot open " + a.index_blob);
+        std::string blob; char buf[1 << 16]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) blob.append(buf, n); fclose(f);
+        if (stitch_index_deserialize(blob.data(), blob.size(), &index) != STITCH_OK) die(stitch_last_error());
+    } else if (stitch_index_build(cn.data(), cs.data(), cl.data(), (uint32_t)names.size(), &index) != STITCH_OK) die(stitch_last_error());
+
+    if (!a.devices.empty()) {
+        // ---- parent of a multi-device run: no GPU call in this process -----------------------------------------------------
+        const std::string path = fastq ? a.reads_fastq : a.reads_fasta;
+        if (path == "-") die("--devices needs the reads in a file (every worker reads its own block)");
+        std::string cat; std::vector<uint64_t> offs(1, 0);
+        { Rec r; while (reads.next(r)) { cat += r.seq; offs.push_back(cat.size()); } }
+        const uint32_t n_all = (uint32_t)(offs.size() - 1), W = (uint32_t)a.devices.size();
+        char tmpl[] = "/tmp/stitch-align-XXXXXX"; const char* dir = mkdtemp(tmpl); if (!dir) die("mkdtemp failed");
+        const std::string blob_path = std::string(dir) + "/index.blob";
+        { size_t len = 0; if (stitch_index_serialize(index, nullptr, &len) != STITCH_OK) die(stitch_last_error()); std::string blob(len, '\0');
+          if (stitch_index_serialize(index, &blob[0], &len) != STITCH_OK) die(stitch_last_error());
+          FILE* f = fopen(blob_path.c_str(), "wb"); if (!f || fwrite(blob.data(), 1, len, f) != len) die("cannot write " + blob_path); fclose(f); }
+        std::vector<pid_t> pids(W); std::vector<std::string> outs(W);
+        for (uint32_t r = 0; r < W; ++r) {
+            uint32_t lo = 0, hi = 0;
+            if (stitch_shard_range((const uint8_t*)cat.data(), offs.data(), n_all, W, r, &lo, &hi) != STITCH_OK) die(stitch_last_error());
+            outs[r] = std::string(dir) + "/rank" + std::to_string(r) + ".sam";
+            std::vector<std::string> av;
+            for (int i = 0; i < argc; ++i) { const std::string k = argv[i]; if (k == "--devices" || k == "--output-format") { ++i; continue; } if (k == "--device") { ++i; continue; } av.push_back(k); }
+            av.insert(av.end(), {"--device", std::to_string(a.devices[r]), "--shard", std::to_string(lo), std::to_string(hi), "--shard-out", outs[r], "--index-blob", blob_path});
+            const pid_t pid = fork();
+            if (pid < 0) die("fork failed");
+            if (pid == 0) { std::vector<char*> cv; for (auto& x : av) cv.push_back(&x[0]); cv.push_back(nullptr); execv("/proc/self/exe", cv.data()); _exit(127); }
+            pids[r] = pid;
+        }
+        bool ok = true;
+        for (uint32_t r = 0; r < W; ++r) { int st = 0; if (waitpid(pids[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; }
+        if (!ok) die("a worker process failed");
+        for (uint32_t r = 0; r < W; ++r) {                 // records in rank order = input order
+            LineReader in(outs[r]); std::string l;
+            while (in.line(l)) { if (l.empty()) continue; if (out.bam) enc.record(out, l); else { out.put(l.data(), l.size()); out.put("\n", 1); } }
+            unlink(outs[r].c_str());
+        }
+        unlink(blob_path.c_str()); rmdir(dir);
+        out.finish();
+        fprintf(stderr, "stitch-align: %u reads on %u devices\n", n_all, W);
+        stitch_index_destroy(index);
+        return 0;
+    }
+    if (worker) { if (!freopen(a.shard_out.c_str(), "w", stdout)) die("cannot write " + a.shard_out); out.bam = false; }
     stitch_ctx* ctx = nullptr;
     if (stitch_ctx_create(a.device, index, &a.o, &ctx) != STITCH_OK) die(stitch_last_error());
 
@@ -352,8 +415,12 @@ int main(int argc, char** argv) {
         n_reads += batch.size(); batch.clear();
         if (!out.bam) fflush(stdout);
     };
-    Rec r;
-    while (reads.next(r)) { batch.push_back(r); if (batch.size() >= a.batch) run_batch(); }
+    Rec r; long rec_no = 0;
+    while (reads.next(r)) {
+        const long k = rec_no++;
+        if (worker && (k < a.shard_lo || k >= a.shard_hi)) { if (k >= a.shard_hi) break; continue; }
+        batch.push_back(r); if (batch.size() >= a.batch) run_batch();
+    }
     run_batch();
     out.finish();
     fprintf(stderr, "stitch-align: %llu reads, %.3f Gcells\n", (unsigned long long)n_reads, cells_total / 1e9);

@@ -1232,6 +1232,37 @@ int stitch_prealign_band(const uint8_t* read, uint32_t read_len, const uint8_t* 
     return full ? 1 : 0;
 }
 
+int stitch_shard_range(const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads, uint32_t world, uint32_t rank, uint32_t* lo, uint32_t* hi) {
+    if (!offsets || (!bases && n_reads) || !lo || !hi || world == 0 || rank >= world) return fail(STITCH_EINVAL, "bad argument");
+    auto same = [&](uint32_t a, uint32_t b) {
+        const uint64_t la = offsets[a + 1] - offsets[a], lb = offsets[b + 1] - offsets[b];
+        return la == lb && memcmp(bases + offsets[a], bases + offsets[b], (size_t)la) == 0;
+    };
+    auto cut = [&](uint32_t r) -> uint32_t {          // first read of rank r's block
+        if (r == 0) return 0;
+        if (r >= world) return n_reads;
+        uint32_t k = (uint32_t)((uint64_t)n_reads * r / world);
+        while (k > 0 && k < n_reads && same(k, k - 1)) ++k;
+        return k;
+    };
+    uint32_t prev = 0, a = 0, b = 0;
+    for (uint32_t r = 0; r <= rank + 1; ++r) { const uint32_t c = std::max(cut(r), prev); if (r == rank) a = c; if (r == rank + 1) b = c; prev = c; }
+    *lo = a; *hi = b;
+    return STITCH_OK;
+}
+
+long stitch_split_at_y(const stitch_chain* in, const stitch_op* in_ops, int32_t mode, uint32_t y_pivot, stitch_chain* out, stitch_op* out_ops, uint32_t cap) {
+    if (!in || !out || (!in_ops && in->ops_len) || (!out_ops && cap)) return fail(STITCH_EINVAL, "null argument");
+    HAln a; a.score = in->score; a.xstart = in->xstart; a.xend = in->xend; a.ystart = in->ystart; a.yend = in->yend; a.xlen = in->xlen; a.ylen = in->ylen;
+    a.start_contig_idx = in->start_contig_idx; a.end_contig_idx = in->end_contig_idx; a.length = in->length;
+    a.ops.assign(in_ops, in_ops + in->ops_len);
+    const HAln r = split_at_y(a, mode, y_pivot);
+    *out = stitch_chain{}; out->score = r.score; out->xstart = r.xstart; out->xend = r.xend; out->ystart = r.ystart; out->yend = r.yend; out->xlen = r.xlen; out->ylen = r.ylen;
+    out->start_contig_idx = r.start_contig_idx; out->end_contig_idx = r.end_contig_idx; out->length = r.length; out->ops_begin = 0; out->ops_len = (uint32_t)r.ops.size();
+    for (size_t k = 0; k < r.ops.size() && k < cap; ++k) out_ops[k] = r.ops[k];
+    return (long)r.ops.size();
+}
+
 int stitch_last_timing(const stitch_ctx* c, stitch_timing* out) {
     if (!c || !out) return fail(STITCH_EINVAL, "null argument");
     *out = c->tm;

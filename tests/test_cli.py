@@ -169,3 +169,28 @@ def test_cli_matches_oracle_sam(cli, tmp_path, extra):
     for rec, line in zip(recs, want):
         f = line.split("\t")
         assert (rec["name"], rec["flag"], rec["pos"] + 1, rec["cigar"] or "*") == (f[0], int(f[1]), int(f[3]), f[5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["-d", "--suboptimal"]])
+def test_two_worker_processes_write_what_one_device_writes(cli, tmp_path, extra):
+    """`--devices A,B`: one worker process per GPU (here both on the one GPU of the test box), the index handed over as the
+    serialized blob, the read stream cut at read-group boundaries (stitch_shard_range), records concatenated in rank order:
+    byte-identical to the single-device output apart from the @PG line (which quotes the command line) — SAM and BAM."""
+    from stitch_amd import synth
+    db = synth.make_db(5, 700, 31)
+    reads = [r.decode() for r in synth.make_reads(db, 31, 250, 9, dup_every=5)]
+    reads[15] = reads[14] = reads[16]                              # a run of identical reads across the middle cut: it must stay on one rank
+    ref = tmp_path / "ref.fa"
+    ref.write_text("".join(f">{n}\n{s.decode()}\n" for n, s in db))
+    fq = tmp_path / "reads.fq"
+    fq.write_text("".join(f"@read_{k}\n{r}\n+\n{'I' * len(r)}\n" for k, r in enumerate(reads)))
+    one = run(cli, "-f", str(fq), "-r", str(ref), "--device", "0", "--batch", "7", *extra).stdout.decode().splitlines()
+    two = run(cli, "-f", str(fq), "-r", str(ref), "--devices", "0,0", "--batch", "7", *extra).stdout.decode().splitlines()
+    strip = lambda ls: [l for l in ls if not l.startswith("@PG")]
+    assert strip(one) == strip(two) and len(strip(one)) > len(reads)
+    three = run(cli, "-f", str(fq), "-r", str(ref), "--devices", "0,0,0", "--batch", "4", *extra).stdout.decode().splitlines()
+    assert strip(one) == strip(three)
+    t1, r1, c1 = read_bam(run(cli, "-f", str(fq), "-r", str(ref), "--output-format", "bam", *extra).stdout)
+    t2, r2, c2 = read_bam(run(cli, "-f", str(fq), "-r", str(ref), "--output-format", "bam", "--devices", "0,0", *extra).stdout)
+    assert r1 == r2 and c1 == c2

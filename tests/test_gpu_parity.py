@@ -65,9 +65,15 @@ def test_golden_multi_contig():  # multi_contig_aligner.rs:465-666 (the tests wh
         assert summary(chains[0]) == expected(t["cases"][0]["expect"]), (t["name"], chains[0])
 
 
-def test_golden_jump_score_priorities():  # multi_contig_aligner.rs:668-737 through double_strand (aligner order differs)
+def test_golden_jump_score_priorities():  # multi_contig_aligner.rs:668-737
+    """The reference adds its aligners as (chr1 fwd, chr1 rev, chr2 fwd); Builder::build_aligners orders a double-strand
+    database as (chr1 fwd, chr2 fwd, chr1 rev, chr2 rev).  chr2's reverse strand (TTTTT) shares nothing with the read, and the
+    five cases are decided by the jump scores' priority (same > opposite > inter), not by aligner order — so the GOLDEN
+    expectation must come out once the product's contig indexes are renamed to the reference's (0 -> 0, 2 -> 1, 1 -> 2); the
+    oracle, built like the product, is compared as well."""
     t = [x for x in MULTI if x["name"] == "test_jump_scores"][0]
     targets = [("chr1", resolve(t["contigs"][0]["seq"])), ("chr2", resolve(t["contigs"][2]["seq"]))]
+    to_ref = {0: 0, 2: 1, 1: 2, 3: 3}
     for case in t["cases"]:
         js, jo, ji = case["jump_scores"]
         kw = dict(mode="local", match_score=1, mismatch_score=-1, gap_open=-100000, gap_extend=-100000)
@@ -80,6 +86,16 @@ def test_golden_jump_score_priorities():  # multi_contig_aligner.rs:668-737 thro
         assert [c.score for c in got] == [c.score for c in want]
         assert summary(got[0], (4, 5)) == (want[0].xstart, want[0].xend, want[0].ystart, want[0].yend, want[0].score,
                                            want[0].start_contig_idx, want[0].cigar(), want[0].length)
+        # ... and the reference's own expectation, in the reference's contig numbering
+        g = got[0]
+        r = stitch_amd.Alignment()
+        for f in stitch_amd.Alignment.__slots__[:-1]:
+            setattr(r, f, getattr(g, f))
+        r.start_contig_idx, r.end_contig_idx = to_ref[g.start_contig_idx], to_ref[g.end_contig_idx]
+        r.operations = [(k, to_ref[a], b) if k == 6 else (k, a, b) for k, a, b in g.operations]
+        e = case["expect"]
+        assert (r.xstart, r.xend, r.ystart, r.yend, r.score, r.start_contig_idx, r.cigar(), r.length) == \
+            (e["xstart"], e["xend"], e["ystart"], e["yend"], e["score"], e["start_contig_idx"], e["cigar"], e["length"]), (case, r)
 
 
 def oracle_key(a):

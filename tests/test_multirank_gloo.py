@@ -54,3 +54,22 @@ def test_shard_range_keeps_duplicate_runs_together():
     assert [shard_range(reads, 2, r) for r in range(2)] == [(0, 4), (4, 6)]
     assert [shard_range(reads, 3, r) for r in range(3)] == [(0, 4), (4, 4), (4, 6)]
     assert [shard_range([b"x"] * 5, 2, r) for r in range(2)] == [(0, 5), (5, 5)]
+
+
+def test_shard_range_blocks_tile_the_stream_for_any_world():
+    """the library's rule (stitch_shard_range): blocks are contiguous, in rank order, cover the stream, and no run of identical
+    reads is cut — for every world size, including more ranks than reads"""
+    import random
+    from stitch_amd.dist import shard_range
+    rng = random.Random(3)
+    for trial in range(30):
+        reads = []
+        while len(reads) < rng.randint(0, 40):
+            r = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 6)))
+            reads += [r] * rng.randint(1, 4)
+        for world in (1, 2, 3, 5, 8, 50):
+            spans = [shard_range(reads, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == len(reads)
+            assert all(spans[k][1] == spans[k + 1][0] for k in range(world - 1)) and all(lo <= hi for lo, hi in spans)
+            for lo, hi in spans:
+                assert lo == 0 or lo == len(reads) or reads[lo] != reads[lo - 1]
