@@ -18,8 +18,8 @@
 //     workgroup barrier in the column loop, and the polled records stay in registers.
 //   * y-suffix records (:431-447) are kept for cells that reach the best score seen so far in ANY contig (mode traceback) or in
 //     their own contig (traceback_all / traceback_from): DESIGN.md "y-suffix records".
-// Eligibility (stitch_api.cpp regs_plan): what fill_local16 admits, and: not circular, every contig <= 64 x RMAX rows,
-// |ge| x 64 x RMAX small enough for lane-tagged scan keys.  Everything else runs fill_local16 / the generic kernel.
+// Eligibility (stitch_api.cpp regs_plan): what fill_local16 admits, and: every contig <= 64 x RMAX rows, gap penalties small
+// enough for 16-bit insertion-chain words and lane-tagged scan keys.  Everything else runs fill_local16 / the generic kernel.
 // Traceback bytes and y-suffix records are stored lane-interleaved (walk_core.h tb_row_offset, V.tb_keyfmt == 2) so that every
 // store instruction writes whole 256-byte lines.  All spins are bounded and end the kernel with an error word, never a hang.
 #include <type_traits>
@@ -65,11 +65,12 @@ struct Col {
     int32_t Tup;                               // new S' word of the row above
     int32_t Iw;                                // insertion chain of the lane's own openers, arriving at the current row
     int32_t dgm; uint32_t pad;                 // row m (register `pad` of its lane): its diagonal candidate, needed for its finalisation
+    int32_t jfix;                              // circular contigs: what row 1's jump word has over the column's (lane 0, consumed by its first row)
 };
 
 // ---- pass 1, one row (register IDX): everything of the cell that needs column j-1 only (dp_core.h row_phase_a_word), written
 // in place; the score of best{diagonal, deletion} is parked in LDS for the insertion merge of pass 2
-template <int IDX>
+template <int IDX, bool CIRC>
 __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32_t& tbw, Col& c, const uint32_t* xw_lane, uint16_t* bs_lane) {
     constexpr int k = IDX & 3;
     const int32_t aw1 = c.aw1, DG = c.DG;                    // prepared by the row above (or the column's prologue)
@@ -89,7 +90,8 @@ __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32
     const bool c1 = word_score(BD) > word_score(DG);         // deletion strictly better than the diagonal
     const int32_t bs2 = c1 ? BD : DG;
     const int32_t X = c1 ? (BD | 0xFFFF) : DG;               // what the jump has to beat (:373-382)
-    const int32_t JW = aw1 + c.JSWm1;
+    int32_t JW = aw1 + c.JSWm1;
+    if (CIRC && k == 3) { JW += c.jfix; c.jfix = 0; }       // (a lane's first row is byte 3 of its top group; only row 1 of the contig has a non-zero term)
     const bool c3 = JW > X;
     int32_t T = c3 ? JW : bs2;
     const bool c4 = T < 0;                                   // x-prefix clip: score 0, length 0
@@ -105,6 +107,7 @@ __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32
 
 struct Col2 {
     int32_t MW, XW, JSW, GE1, GO1; uint32_t q;
+    int32_t JSW1; uint32_t row1_idx; bool lane0;   // circular contigs: row 1's jump word; row 1 = register row1_idx of lane 0
     uint32_t tbn;                              // the traceback codes of the NEXT group (read from LDS a group ahead)
     int32_t Iw;                                // the insertion chain's word AT the current row ...
     uint32_t extn;                             // ... and TBB_IEXT if it got there by an extension (else 0)
@@ -114,7 +117,7 @@ struct Col2 {
 
 // ---- pass 2, one row: the merge of the insertion into the cell where it changes it (dp_core.h row_phase_c_word: beats
 // best{diagonal, deletion}, is not beaten by the jump), the chain's "extended" bit, and the chain's step to the next row
-template <int IDX>
+template <int IDX, bool CIRC>
 __device__ __forceinline__ void row_pass2(uint32_t& Sreg, uint32_t& tbw, Col2& c, const uint32_t* xw_lane, const uint16_t* bs_lane, const bool real) {
     constexpr int k = IDX & 3;
     const int32_t T = (int32_t)Sreg, Iw = c.Iw;
@@ -131,7 +134,7 @@ __device__ __forceinline__ void row_pass2(uint32_t& Sreg, uint32_t& tbw, Col2& c
         const uint32_t xb = (xw_lane[(IDX >> 2) * 64] >> (8 * k)) & 0xFFu;
         RowW ra;
         ra.T = T; ra.mvT = (tbw >> (8 * k)) & 7u;
-        ra.JW = c.JSW + (xb == c.q ? c.MW : c.XW);
+        ra.JW = ((CIRC && c.lane0 && c.row1_idx == (uint32_t)IDX) ? c.JSW1 : c.JSW) + (xb == c.q ? c.MW : c.XW);
         ra.bs2h = (int32_t)(((uint32_t)bs_lane[IDX * 64] << 16) | 0xFFFFu);
         uint32_t mv;
         Sreg = (uint32_t)row_phase_c_word(ra, bi, il, mv);
@@ -171,7 +174,7 @@ __device__ __forceinline__ void group_records(Recs& R, const uint32_t t3, const 
 }  // namespace
 
 // NQ = granule registers per lane: 1 for up to 64 active contigs, 4 for up to 256
-template <int NQ>
+template <int NQ, bool CIRC>
 __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restrict__ jobs, FillShared sh, uint32_t G) {
     // (the quotient comes out of vector arithmetic: tell the compiler it is uniform, so that everything read through V is scalar)
     const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / G));
@@ -247,6 +250,10 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     }
     if (lane == 0) V.Lx[(size_t)c * (n + 1)] = sh.lx0[c];
     int32_t vrun = sh.base0[c].score;                                     // the contig's running maximum over columns < j
+    // cell (m, j-1), for the zero-cost end-to-start jump of a circular contig (get_jump_score_and_len :258-289)
+    const uint32_t trm = cd.troff + m - 1;
+    bool rowm_xsuf = sh.Smove0[trm] == TB_XCLIP_SUFFIX; int32_t rowm_S = sh.S0[trm]; uint32_t rowm_len = sh.Slen0[trm];
+    const int32_t circular = P.circular;
     int32_t gmax = 0;                                                     // best score of any contig in columns < j (row 0 holds 0)
     // the contigs' column arg-max of column j-1, lane l holding active contigs l, l + 64, ...: {column, score, len, from} granules
     unsigned long long gv[NQ]; uint32_t actid[NQ];      // ... and their aligner ids
@@ -329,9 +336,14 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                 const int32_t sc = (int32_t)((b >> 32) & 0xFFFFu) + jump_inter;
                 if (sc > ji.score) { ji.score = sc; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = act_of(kw); ji.from = (uint32_t)b & 0xFFFFu; }
             }
-            if (lane == 0) { jt_idx[(size_t)c * (n + 1) + j] = ji.idx; jt_from[(size_t)c * (n + 1) + j] = ji.from; }
         }
+        // Row 1 of a circular contig may take the zero-cost jump from row m of the previous column instead (dp_core.h
+        // local_row1_circ); the walk learns it from bit 31 of the column's jump-table entry
+        bool circ = false;
+        if (CIRC) { ColCtx cc; cc.jump = ji; cc.circ_ok = (circular && !rowm_xsuf) ? 1 : 0; cc.circ_score = rowm_S; cc.circ_len = rowm_len + 1; circ = local_row1_circ(cc); }
+        if (lane == 0) { jt_idx[(size_t)c * (n + 1) + j] = ji.idx | (circ ? JT_CIRC_BIT : 0u); jt_from[(size_t)c * (n + 1) + j] = ji.from; }
         const int32_t JSW = __builtin_amdgcn_readfirstlane(word_make(ji.score, ji.len));
+        const int32_t JSW1 = circ ? __builtin_amdgcn_readfirstlane(word_make(rowm_S, rowm_len + 1)) : JSW;
         // y-suffix records are kept for cells whose score reaches ybase (never for a zero word)
         const int32_t ybase = ymode_global ? gmax : vrun;
         const int32_t ythr = ybase > 0 ? (int32_t)((uint32_t)ybase << 16) : 1;
@@ -350,14 +362,15 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         cx.Tup = CHAIN_JUNK_T;                                            // (stands in for the row above the lane's first row: see the scan)
         cx.Iw = CHAIN_NONE;
         cx.dgm = 0; cx.pad = pad;
+        cx.jfix = lane == 0 ? JSW1 - JSW : 0;
         cx.xw = xw_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];                 // the lane's first row is byte 3 of its top group
         cx.xwn = xw_lane[(gl_x > 1 ? gl_x - 2 : 0) * 64];                // ... and the group below it
         cx.aw1 = (cx.xw >> 24) == q ? cx.MW1 : cx.XW1;
         // the row above a lane's first row is the previous lane's last row: register 0; row 0 for lane 0 (score 0, length 0 in Local mode)
         cx.DG = from_prev_lane((int)S[0], 0) + cx.aw1;
 #define P1(g) if ((uint32_t)(g) < gl_x) { uint32_t tbw; \
-            row_pass1<4 * (g) + 3>(S[4 * (g) + 3], D[4 * (g) + 3], tbw, cx, xw_lane, bs_lane); row_pass1<4 * (g) + 2>(S[4 * (g) + 2], D[4 * (g) + 2], tbw, cx, xw_lane, bs_lane); \
-            row_pass1<4 * (g) + 1>(S[4 * (g) + 1], D[4 * (g) + 1], tbw, cx, xw_lane, bs_lane); row_pass1<4 * (g)>(S[4 * (g)], D[4 * (g)], tbw, cx, xw_lane, bs_lane); \
+            row_pass1<4 * (g) + 3, CIRC>(S[4 * (g) + 3], D[4 * (g) + 3], tbw, cx, xw_lane, bs_lane); row_pass1<4 * (g) + 2, CIRC>(S[4 * (g) + 2], D[4 * (g) + 2], tbw, cx, xw_lane, bs_lane); \
+            row_pass1<4 * (g) + 1, CIRC>(S[4 * (g) + 1], D[4 * (g) + 1], tbw, cx, xw_lane, bs_lane); row_pass1<4 * (g), CIRC>(S[4 * (g)], D[4 * (g)], tbw, cx, xw_lane, bs_lane); \
             tb_lane[(g) * 64] = tbw; }
         REP20(P1)
 #undef P1
@@ -401,6 +414,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         // records, y-suffix records and the traceback dword ------------------------------------------------------------------------------
         Col2 c2;
         c2.MW = MW; c2.XW = XW; c2.JSW = JSW; c2.GE1 = GE1; c2.GO1 = GO1; c2.q = q;
+        c2.JSW1 = JSW1; c2.row1_idx = 4u * gtop - 1u; c2.lane0 = lane == 0;
         c2.Iw = Iin; c2.extn = extin; c2.rg4 = rg4_x;
         c2.tbn = tb_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];
         c2.lastcol = (uint32_t)__builtin_amdgcn_readfirstlane(lastcol ? 1 : 0);
@@ -414,8 +428,8 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         // k <= pad (k < pad: no row at all; k == pad: row m itself)
 #define P2(g) if ((uint32_t)(g) < gl_x) { \
             uint32_t tbw = c2.tbn; if ((g) > 0) c2.tbn = tb_lane[((g) > 0 ? (g) - 1 : 0) * 64]; \
-            row_pass2<4 * (g) + 3>(S[4 * (g) + 3], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 3u < pad)); row_pass2<4 * (g) + 2>(S[4 * (g) + 2], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 2u < pad)); \
-            row_pass2<4 * (g) + 1>(S[4 * (g) + 1], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 1u < pad)); row_pass2<4 * (g)>(S[4 * (g)], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 0u < pad)); \
+            row_pass2<4 * (g) + 3, CIRC>(S[4 * (g) + 3], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 3u < pad)); row_pass2<4 * (g) + 2, CIRC>(S[4 * (g) + 2], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 2u < pad)); \
+            row_pass2<4 * (g) + 1, CIRC>(S[4 * (g) + 1], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 1u < pad)); row_pass2<4 * (g), CIRC>(S[4 * (g)], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 0u < pad)); \
             const uint32_t t3 = ((g) == 0 && mine && 3u <= pad) ? 0u : S[4 * (g) + 3], t2 = ((g) == 0 && mine && 2u <= pad) ? 0u : S[4 * (g) + 2]; \
             const uint32_t t1 = ((g) == 0 && mine && 1u <= pad) ? 0u : S[4 * (g) + 1], t0 = ((g) == 0 && mine) ? 0u : S[4 * (g)]; \
             group_records(R, t3, t2, t1, t0, rowbase + (nrows - 4u - 4u * (g))); \
@@ -485,6 +499,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             }
             if (Sm > cb_.v) { cb_.v = Sm; cb_.row = m; cb_.len = Slm; }
             if (cb_.v > vrun) vrun = cb_.v;
+            rowm_xsuf = mvm == MK_XSUF; rowm_S = Sm; rowm_len = Slm;
             if (lane == 0) {
                 const unsigned long long gran = ((unsigned long long)j << 48) | ((unsigned long long)(uint32_t)(cb_.v & 0xFFFF) << 32) | ((unsigned long long)((cb_.len + 1u) & 0xFFFFu) << 16) | (cb_.row & 0xFFFFu);
                 __hip_atomic_store(xchg + (size_t)(j & 1u) * C + kmine, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -500,25 +515,28 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             V.Sn[roff + row] = word_score((int32_t)rec.x); V.SnLen[roff + row] = word_len((int32_t)rec.x); V.Ly[roff + row] = rec.y;
         }
     }
-    (void)gtop;
 }
 
 uint32_t fill_regs_rows_per_wave() { return 64u * RMAX; }
 // workgroups of `waves` waves one CU holds at once, as the runtime's occupancy calculator sees it (the host never launches more
 // workgroups than CUs x this: all workgroups of a read must be resident, they wait for each other every column)
 int fill_regs_workgroups_per_cu(uint32_t waves) {
-    int n1 = 0, n4 = 0;
-    // (more than 64 KiB of dynamic LDS has to be allowed explicitly)
-    if (hipFuncSetAttribute((const void*)fill_regs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)fill_regs_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, fill_regs_kernel<1>, (int)waves * 64, (size_t)waves * LDS_PER_WAVE) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, fill_regs_kernel<4>, (int)waves * 64, (size_t)waves * LDS_PER_WAVE) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return n1 < n4 ? n1 : n4;
+    const void* kernels[4] = {(const void*)fill_regs_kernel<1, false>, (const void*)fill_regs_kernel<4, false>, (const void*)fill_regs_kernel<1, true>, (const void*)fill_regs_kernel<4, true>};
+    int least = 1 << 30;
+    for (const void* k : kernels) {
+        // (more than 64 KiB of dynamic LDS has to be allowed explicitly)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, (int)waves * 64, (size_t)waves * LDS_PER_WAVE) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        least = nb < least ? nb : least;
+    }
+    return least;
 }
-// max_nact: the largest number of active contigs of any job of the launch
-void launch_fill_regs(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t waves, uint32_t max_nact, const FillShared& sh, hipStream_t stream) {
-    if (max_nact <= 64) hipLaunchKernelGGL(fill_regs_kernel<1>, dim3(n_jobs * G), dim3(waves * 64), (size_t)waves * LDS_PER_WAVE, stream, d_jobs, sh, G);
-    else hipLaunchKernelGGL(fill_regs_kernel<4>, dim3(n_jobs * G), dim3(waves * 64), (size_t)waves * LDS_PER_WAVE, stream, d_jobs, sh, G);
+// max_nact: the largest number of active contigs of any job of the launch; circular: opts.circular
+void launch_fill_regs(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream) {
+    const dim3 grid(n_jobs * G), block(waves * 64); const size_t lds = (size_t)waves * LDS_PER_WAVE;
+    if (max_nact <= 64) { if (circular) hipLaunchKernelGGL((fill_regs_kernel<1, true>), grid, block, lds, stream, d_jobs, sh, G); else hipLaunchKernelGGL((fill_regs_kernel<1, false>), grid, block, lds, stream, d_jobs, sh, G); }
+    else { if (circular) hipLaunchKernelGGL((fill_regs_kernel<4, true>), grid, block, lds, stream, d_jobs, sh, G); else hipLaunchKernelGGL((fill_regs_kernel<4, false>), grid, block, lds, stream, d_jobs, sh, G); }
 }
 
 }  // namespace stitch

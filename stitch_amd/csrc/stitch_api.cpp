@@ -45,7 +45,7 @@ constexpr size_t PIN_BYTES = (size_t)64 << 20;   // pinned staging buffer for re
 constexpr uint32_t TILE_ROWS = 512;   // 64 lanes x 8 rows (Local-mode kernel; the generic one uses 256): contig row blocks are padded to this
 void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, uint32_t slots_cap, const FillShared& sh, hipStream_t stream);
 uint32_t fill_local16_max_slots();
-void launch_fill_regs(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t waves, uint32_t max_nact, const FillShared& sh, hipStream_t stream);
+void launch_fill_regs(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
 uint32_t fill_regs_rows_per_wave();
 int fill_regs_workgroups_per_cu(uint32_t waves);
 }  // namespace stitch
@@ -395,11 +395,11 @@ bool local16_ok(const stitch_ctx& c, const Job& jb) {
 }
 
 // The register-resident Local-mode kernel (fill_regs.hip): one wave per active contig, REGS_WAVES waves per workgroup.  Returns the
-// workgroups a read needs (0: not applicable — circular contigs, a contig longer than a wave holds, a gap-extension penalty
+// workgroups a read needs (0: not applicable — a contig longer than a wave holds, a gap-extension penalty
 // too large for lane-tagged scan keys, more workgroups than the device holds at once, or a read too small to be worth a team).
 constexpr uint32_t REGS_WAVES = 4;
 uint32_t regs_plan(const stitch_ctx& c, const Job& jb) {
-    if (c.knobs.no_regs || c.regs_wg_per_cu <= 0 || !local16_ok(c, jb) || c.opts.circular) return 0;
+    if (c.knobs.no_regs || c.regs_wg_per_cu <= 0 || !local16_ok(c, jb)) return 0;
     if (c.opts.gap_extend < -1024 || c.opts.gap_open + c.opts.gap_extend < -8000) return 0;      // (16-bit insertion-chain words, fill_regs.hip)
     uint64_t rows = 0;
     for (uint32_t a : jb.act) { if (c.al[a].m > fill_regs_rows_per_wave()) return 0; rows += c.al[a].m; }
@@ -677,7 +677,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         // workgroup per read (nothing waits across workgroups there), or on the generic kernel if a read's tiles exceed one slot table.
         uint32_t kind = regs_G ? 2u : fast ? 1u : 0u;
         for (int attempt = 0;; ++attempt) {
-        if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, nj, G, REGS_WAVES, mx, sh, c.stream); }
+        if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, nj, G, REGS_WAVES, mx, c.opts.circular != 0, sh, c.stream); }
         else if (kind == 1u) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, c.stream);
         else launch_fill(d_views, nj, waves, sh, c.stream);
         HIP_TRY(hipGetLastError());

@@ -1,8 +1,8 @@
 """The register-resident Local-mode kernel (stitch_amd/csrc/fill_regs.hip) against the golden vectors and the oracle.
 
 By default only reads with at least 2048 active contig rows go to it (smaller ones run fill_local16.hip), so the parity suite's
-small cases would never reach it: here STITCH_REGS_MIN_ROWS=0 sends EVERY eligible read to it (Local mode, not circular,
-contigs of at most 5120 rows) and the scenarios of tests/test_gpu_parity.py are replayed.  Contig lengths around the lane
+small cases would never reach it: here STITCH_REGS_MIN_ROWS=0 sends EVERY eligible read to it (Local mode, contigs of at most
+5120 rows) and the scenarios of tests/test_gpu_parity.py are replayed.  Contig lengths around the lane
 mapping's edges (1 row, 3, 4, 5, 255..257, 1300 rows: groups of four rows dealt to 64 lanes) get a test of their own."""
 import random
 
@@ -80,6 +80,15 @@ def test_more_than_64_active_contigs():
 
 def test_iupac_codes_n_and_lower_case():
     P.test_iupac_codes_n_and_lower_case()
+
+
+def test_circular_realignment():
+    """row 1 of a circular contig may continue from row m of the previous column at no cost; origin re-alignment on top"""
+    P.test_circular_realignment()
+
+
+def test_cfg5_shape_many_circular_contigs_suboptimal():
+    P.test_cfg5_shape_many_circular_contigs_suboptimal()
 
 
 def test_long_contigs_near_the_register_capacity():
