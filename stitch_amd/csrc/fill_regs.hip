@@ -36,6 +36,21 @@ constexpr int NG = RMAX / 4;                   // groups of four rows: one trace
 static_assert(RMAX == 80, "the group blocks below are written out for 20 groups");
 constexpr uint32_t RSRC_WORD3 = 0x00020000u;   // raw buffer descriptor, gfx94x / gfx950
 constexpr int AUX_NT = 2;                      // streamed once: non-temporal
+constexpr int AUX_SC1 = 16;                    // agent-scope coherence (what an agent-scope atomic load carries on gfx94x / gfx950)
+constexpr int AUX_VOLATILE = (int)0x80000000u; // compiler-side: never merged, hoisted or dropped
+#ifndef STITCH_POLL_SLEEP
+#define STITCH_POLL_SLEEP 4                    // x 64 clocks between two looks at the granules
+#endif
+
+// In-kernel stamps (diagnostic build only, -DSTITCH_PROFILE): per-wave cycle sums of the column loop's sections, added up per read
+// in the debug area behind V.err.  Never enabled in the product build.
+#ifdef STITCH_PROFILE
+#define RPROF_DECL uint32_t pf_t = (uint32_t)__builtin_readcyclecounter(), pf_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RPROF(k) { const uint32_t pf_n = (uint32_t)__builtin_readcyclecounter(); pf_sum[k] += pf_n - pf_t; pf_t = pf_n; }
+#else
+#define RPROF_DECL
+#define RPROF(k)
+#endif
 
 // per wave in LDS: NG x 64 words of bases (constant), NG x 64 words of traceback codes (pass 1 -> pass 2), RMAX x 64 scores of
 // best{diagonal, deletion} (pass 1 -> the insertion merge of pass 2)
@@ -45,11 +60,21 @@ constexpr uint32_t LDS_XW = 0, LDS_TB = NG * 64 * 4, LDS_BS = 2 * NG * 64 * 4, L
 // insertion candidate, dp_core.h phase B) is carried as a WORD like S and D (score << 16 | length): one step down a lane is
 //   ext = I + GE1, open = S'(row above) + GO1, I = score(ext) >= score(open) ? ext : open     (the extension wins ties, :321)
 // i.e. two adds, a compare of the high halves and a select.  Every row has an opener with score >= go + ge (S' >= 0), so the
-// chain's score stays >= go + ge + ge and the 16-bit field cannot wrap (regs_plan: ge >= -1024, go + ge >= -8000).  Pass 1 runs
-// the chain of the lane's OWN openers only (what arrives from the lanes above is not known yet); its value behind the lane's
-// last row crosses the lanes as a position-normalised key in a lane-tagged DPP prefix maximum; pass 2 runs the true chain.
+// chain's score stays >= go + ge + ge and the 16-bit field cannot wrap (regs_plan: ge >= -1024, go + ge >= -8000).
+//
+// Two passes per column.  Pass 1 runs the chain L of the lane's OWN openers (what arrives from the lanes above is not known
+// yet) and already merges it into the cells.  L's value behind the lane's last row crosses the lanes as a position-normalised
+// key in a lane-tagged DPP prefix maximum, which gives every lane X = the chain arriving at its first row.  The true chain is
+//   X carried down (score + ge, length + 1 per row) as long as no opener has beaten it STRICTLY, and L from that row on:
+// the extension wins ties, so X survives until an opener is strictly better; at that row L is that very opener (it beats
+// L's own extension, which is <= X's), and from there both recurrences are the same.  Pass 2 therefore visits a lane's rows
+// from the top only WHILE X IS ALIVE in some lane of the wave — in most contigs and columns a few rows; only below a
+// high-scoring path the chain lives on for score / |ge| rows — and repairs there what pass 1 assumed: the "extended" bit (an
+// alive X arrived by extension) and the merge (with X instead of L; when X changes a cell, the result does not depend on
+// what L did to it: row_alive).  An opener taken from a cell that the insertion itself produced never beats the extension
+// (go <= 0: regs_plan), so both passes may open from the row's final word.
 constexpr int32_t CHAIN_NONE = (int32_t)0x92A00000u;      // word(-28000, 0): "no chain yet", cannot wrap when extended
-constexpr int32_t CHAIN_JUNK_T = (int32_t)0xC1800000u;    // word(-16000, 0): stands in for the unknown row above a lane's first row
+constexpr int32_t SUP_NONE = (int32_t)0xA2400000u;        // word(-24000, 0): "no row above": its opener (>= -32000) is below every X (>= -28000)
 
 __device__ __forceinline__ int32_t chain_step(const int32_t I, const int32_t Tabove, const int32_t GE1, const int32_t GO1) {
     const int32_t ext = I + GE1, open = Tabove + GO1;
@@ -62,14 +87,12 @@ struct Col {
     uint32_t q;                                // y[j-1]
     int32_t aw1, DG;                           // the current row's (match | mismatch) word and diagonal candidate: old S word of the row above + aw1
     uint32_t xw, xwn;                          // four bases: the group of the NEXT row; the group below it (read from LDS a group ahead)
-    int32_t Tup;                               // new S' word of the row above
-    int32_t Iw;                                // insertion chain of the lane's own openers, arriving at the current row
     int32_t dgm; uint32_t pad;                 // row m (register `pad` of its lane): its diagonal candidate, needed for its finalisation
     int32_t jfix;                              // circular contigs: what row 1's jump word has over the column's (lane 0, consumed by its first row)
 };
 
 // ---- pass 1, one row (register IDX): everything of the cell that needs column j-1 only (dp_core.h row_phase_a_word), written
-// in place; the score of best{diagonal, deletion} is parked in LDS for the insertion merge of pass 2
+// in place; the score of best{diagonal, deletion} is parked in LDS for the insertion merges
 template <int IDX, bool CIRC>
 __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32_t& tbw, Col& c, const uint32_t* xw_lane, uint16_t* bs_lane) {
     constexpr int k = IDX & 3;
@@ -100,73 +123,88 @@ __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32
     tbw = k == 3 ? code : ((tbw << 8) | code);               // byte k of the group's dword: register 4g+3 first, 4g last
     bs_lane[IDX * 64] = (uint16_t)((uint32_t)bs2 >> 16);
     if (IDX < 4) { if (c.pad == (uint32_t)IDX) c.dgm = DG; }
-    c.Iw = chain_step(c.Iw, c.Tup, c.GE1, c.GO1);           // ... arriving at this row (unused here), and on to the next below
-    c.Tup = T;
     Sreg = (uint32_t)T; Dreg = (uint32_t)BD;
 }
 
+
+// ---- pass 1b: the chain L of the lane's own openers.  chain_row steps it over one row (the chain arriving at the row is kept
+// for the merge, its "extended" bit goes into the group's traceback dword); merge_row merges a chain word into the cell where it
+// changes it (dp_core.h row_phase_c_word: beats best{diagonal, deletion}, is not beaten by the jump).  The chain opens from S
+// WITHOUT its own insertion candidate (dp_core.h, phase B), i.e. from the words as pass 1 left them: a group's four steps are
+// taken first, then ONE test whether any of its cells has to be merged (a branch per row costs more than the row's arithmetic).
+// (The chain's values at column n are an output, the fix-up kernel reads them: the kernel recomputes them from the final words
+// after the column loop rather than carry a test for the last column through every row of every column.)
 struct Col2 {
-    int32_t MW, XW, JSW, GE1, GO1; uint32_t q;
-    int32_t JSW1; uint32_t row1_idx; bool lane0;   // circular contigs: row 1's jump word; row 1 = register row1_idx of lane 0
+    int32_t GE1, GO1;
     uint32_t tbn;                              // the traceback codes of the NEXT group (read from LDS a group ahead)
     int32_t Iw;                                // the insertion chain's word AT the current row ...
     uint32_t extn;                             // ... and TBB_IEXT if it got there by an extension (else 0)
-    uint32_t lastcol; uint32_t rg4;            // j == n; 4 x (index of register 0's row in the job's linear row arrays)
-    __amdgpu_buffer_rsrc_t rS; uint32_t oSlen, oIval, oIlen;          // the last column's int32 arrays: one descriptor, byte offsets from V.S
 };
-
-// ---- pass 2, one row: the merge of the insertion into the cell where it changes it (dp_core.h row_phase_c_word: beats
-// best{diagonal, deletion}, is not beaten by the jump), the chain's "extended" bit, and the chain's step to the next row
-template <int IDX, bool CIRC>
-__device__ __forceinline__ void row_pass2(uint32_t& Sreg, uint32_t& tbw, Col2& c, const uint32_t* xw_lane, const uint16_t* bs_lane, const bool real) {
+template <int IDX>
+__device__ __forceinline__ int32_t chain_row(const uint32_t Sreg, uint32_t& tbw, Col2& c) {
     constexpr int k = IDX & 3;
-    const int32_t T = (int32_t)Sreg, Iw = c.Iw;
+    const int32_t Iw = c.Iw;
     tbw |= c.extn << (8 * k);
-    // the chain's step to the row below: it opens from S WITHOUT its own insertion candidate (dp_core.h, phase B), i.e. from T
-    // as pass 1 left it — taken first, so that the merge below can overwrite the row's register in place
-    const int32_t ext = Iw + c.GE1, open = T + c.GO1;
-    const bool isext = word_score(ext) >= word_score(open);
+    const int32_t ext = Iw + c.GE1, open = (int32_t)Sreg + c.GO1;
+    const bool isext = word_score(ext) >= word_score(open);  // the extension wins ties (:321)
     c.Iw = isext ? ext : open;
     c.extn = isext ? (uint32_t)TBB_IEXT : 0u;                // "I extended" is a property of the NEXT row's cell
-    // the insertion can only change the cell if its score reaches the cell's (T >= 0, so a negative insertion never does)
-    if (__builtin_expect(__ballot(word_score(Iw) >= word_score(T)) != 0ull, 0)) {
-        const int32_t bi = word_score(Iw); const uint32_t il = word_len(Iw);
-        const uint32_t xb = (xw_lane[(IDX >> 2) * 64] >> (8 * k)) & 0xFFu;
-        RowW ra;
-        ra.T = T; ra.mvT = (tbw >> (8 * k)) & 7u;
-        ra.JW = ((CIRC && c.lane0 && c.row1_idx == (uint32_t)IDX) ? c.JSW1 : c.JSW) + (xb == c.q ? c.MW : c.XW);
-        ra.bs2h = (int32_t)(((uint32_t)bs_lane[IDX * 64] << 16) | 0xFFFFu);
-        uint32_t mv;
-        Sreg = (uint32_t)row_phase_c_word(ra, bi, il, mv);
-        tbw = (tbw & ~(7u << (8 * k))) | (mv << (8 * k));
-    }
-    if (__builtin_expect(c.lastcol != 0u, 0)) {
-        // column n: the int32 arrays the fix-up kernel reads (single_contig_aligner.rs:453-555)
-        if (real) {
-            const uint32_t vo = c.rg4 - 4u * IDX;
-            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score((int32_t)Sreg), c.rS, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len((int32_t)Sreg), c.rS, vo, c.oSlen, 0);
-            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score(Iw), c.rS, vo, c.oIval, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len(Iw), c.rS, vo, c.oIlen, 0);
-        }
-    }
+    return Iw;
+}
+// The merge of a chain word I into a cell whose score it reaches (m: score(I) >= score(S), S >= 0) is short.  Written out,
+// row_phase_c_word with bi = score(I) >= score(S): the clamp does nothing (bi >= 0), BI = I; the jump cannot beat it (c5 false:
+// the jump's score is <= the cell's, which took the jump if it was better, <= bi); the result is not negative (c6 false).  So
+//   c2 = score(I) > score(best{diagonal, deletion})  ?  (I, MK_INS)  :  the cell as it is
+// and for a cell the test does not admit, row_phase_c_word changes nothing (c2 false, or the jump / the clip win again).
+// The score of best{diagonal, deletion} comes from LDS, where pass 1 parked it.
+template <int IDX>
+__device__ __forceinline__ void merge_row(uint32_t& Sreg, uint32_t& tbw, const bool m, const int32_t Iw, const uint16_t* bs_lane) {
+    constexpr int k = IDX & 3;
+    const int32_t bs = (int32_t)(int16_t)bs_lane[IDX * 64];
+    const unsigned long long c2 = __ballot(m && word_score(Iw) > bs);
+    const uint32_t ntb = (tbw & ~(7u << (8 * k))) | ((uint32_t)MK_INS << (8 * k));
+    // (selected IN PLACE: the register allocator otherwise gives the merged value a register of its own and copies every row's
+    // word there and back on the path that does not merge)
+    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(Sreg) : "v"(Iw), "s"(c2));
+    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tbw) : "v"(ntb), "s"(c2));
 }
 
-// the lane's running records over a contig's column (rows below m): the largest S word and the topmost row holding it (x-suffix
-// running max :406-429); the topmost row holding the largest score, and its length (column arg-max :677-697)
-struct Recs { uint32_t bw, xrow, r1, len1; };
-
-__device__ __forceinline__ void group_records(Recs& R, const uint32_t t3, const uint32_t t2, const uint32_t t1, const uint32_t t0, const uint32_t row3) {
-    uint32_t g4 = t3 > t2 ? t3 : t2; g4 = t1 > g4 ? t1 : g4; g4 = t0 > g4 ? t0 : g4;
-    if (g4 > R.bw) {
-        const uint32_t kk = t3 == g4 ? 0u : t2 == g4 ? 1u : t1 == g4 ? 2u : 3u;            // rows down from the group's top row
-        R.xrow = row3 + kk;
-        if ((g4 >> 16) > (R.bw >> 16) || R.r1 == 0xFFFFFFFFu) {
-            const uint32_t s4 = g4 >> 16;
-            const uint32_t k1 = (t3 >> 16) == s4 ? 0u : (t2 >> 16) == s4 ? 1u : (t1 >> 16) == s4 ? 2u : 3u;
-            R.r1 = row3 + k1;
-            R.len1 = (k1 == 0u ? t3 : k1 == 1u ? t2 : k1 == 2u ? t1 : t0) & 0xFFFFu;
-        }
-        R.bw = g4;
+// ---- pass 2, one row of a group in which the chain X that arrived at the lane's first row is still alive in some lane
+struct ColA {
+    int32_t GE1, GO1;
+    int32_t X;                                 // the chain carried down to the current row
+    int32_t Sup;                               // final word of the row above (SUP_NONE above the lane's first row)
+    uint32_t xext;                             // TBB_IEXT if X got to the current row by an extension (the first row: from the scan)
+    bool alive;                                // no opener has strictly beaten X so far
+};
+template <int IDX>
+__device__ __forceinline__ void row_alive(uint32_t& Sreg, uint32_t& tbw, ColA& c, const uint16_t* bs_lane) {
+    constexpr int k = IDX & 3;
+    const int32_t Xw = c.X;
+    const int32_t open = c.Sup + c.GO1;
+    c.alive = c.alive && !(word_score(open) > word_score(Xw));
+    const uint32_t bit = k == 3 ? c.xext : (uint32_t)TBB_IEXT;               // (a lane's first row is byte 3 of its top group)
+    tbw |= c.alive ? bit << (8 * k) : 0u;                                    // pass 1b left the bit of the lane's own chain: 0 in a first row
+    const bool mx = c.alive && word_score(Xw) >= word_score((int32_t)Sreg);
+    if (__builtin_expect(__ballot(mx) != 0ull, 0)) {
+        // X reaches the cell's score.  If it beats best{diagonal, deletion} the cell becomes X whatever pass 1b made of it; if
+        // it does not, the lane's own chain (score <= X's) did not either, and the cell is as pass 1 left it
+        merge_row<IDX>(Sreg, tbw, mx, Xw, bs_lane);
     }
+    c.Sup = (int32_t)Sreg;
+    c.X = Xw + c.GE1;
+    if (k == 3) c.xext = (uint32_t)TBB_IEXT;
+}
+
+// the lane's running records over a contig's column (rows below m): the largest S word and the group of four rows that held it
+// first; the group that first held the largest score.  Which row of which lane that is, the epilogue works out for the one
+// lane that matters (x-suffix running max :406-429: largest word, topmost row; column arg-max :677-697: largest score, topmost row)
+struct Recs { uint32_t bw, gw, g1; };
+
+__device__ __forceinline__ void group_records(Recs& R, const uint32_t g4, const uint32_t g) {
+    R.gw = g4 > R.bw ? g : R.gw;
+    R.g1 = (g4 >> 16) > (R.bw >> 16) ? g : R.g1;
+    R.bw = g4 > R.bw ? g4 : R.bw;
 }
 
 #define REP20(X) X(19) X(18) X(17) X(16) X(15) X(14) X(13) X(12) X(11) X(10) X(9) X(8) X(7) X(6) X(5) X(4) X(3) X(2) X(1) X(0)
@@ -180,6 +218,9 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / G));
     const JobView& V = jobs[job];
     const uint32_t part = blockIdx.x - job * G;
+#ifdef STITCH_EXP_PRIO
+    if (job & 1u) __builtin_amdgcn_s_setprio(2);       // experiment: every other read's team has priority on the SIMDs it shares
+#endif
     const DpParams P = V.P;
     const uint32_t n = V.n, nact = V.nact, Rtot = V.Rtot, C = V.C;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform, provably)
@@ -188,7 +229,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     uint8_t* const s_wave = s_dyn + (size_t)wave * LDS_PER_WAVE;
 
     // ---- this wave's contig: active contig number (part * RW + wave) ------------------------------------------------------------
-    const uint32_t kmine = part * RW + (uint32_t)wave;
+    const uint32_t kmine = (uint32_t)__builtin_amdgcn_readfirstlane((int)(part * RW + (uint32_t)wave));      // (wave-uniform, provably)
     if (kmine >= nact) return;                        // (more waves than contigs: nobody waits for this wave)
     const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)V.act[kmine]);
     ContigDesc cd = V.cd[c];
@@ -270,25 +311,63 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     // descriptors of the arrays written with buffer stores (scalar base + lane offset: no address arithmetic in vector registers)
     const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((uint8_t*)V.D + 8ull * roff, 0, 0x7FFFFFFF, RSRC_WORD3);
     const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(V.S, 0, 0x7FFFFFFF, RSRC_WORD3);
+    const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void*)V.xchg, 0, 0x7FFFFFFF, RSRC_WORD3);
     const uint32_t oSlen = (uint32_t)((const uint8_t*)V.Slen - (const uint8_t*)V.S), oIval = (uint32_t)((const uint8_t*)V.Ival - (const uint8_t*)V.S), oIlen = (uint32_t)((const uint8_t*)V.Ilen - (const uint8_t*)V.S);
+    // ---- the insertion chain across the lanes: E = the chain of a lane's own openers as it arrives BEHIND the lane's last row,
+    // exitext = whether it got there by an extension; Iin / extin = what arrives at this lane's first row
+    auto chain_across_lanes = [&](const int32_t E, const bool exitext, const int32_t pos_x, const uint32_t gl_x, int32_t& Iin, uint32_t& extin) __attribute__((always_inline)) {
+        const int32_t pos_exit = pos_x + 1;                           // 1-based position of the row behind this lane's last row
+        int32_t nk = word_score(E) - ge * pos_exit;
+        if (gl == 0) nk = SCAN_LOW;                                   // lanes without rows
+        int32_t kt = (int32_t)(((uint32_t)nk << 6) | (uint32_t)(63 - lane));
+        { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 1>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 2>(INT32_MIN, kt); kt = o > kt ? o : kt; }
+        { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 4>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 8>(INT32_MIN, kt); kt = o > kt ? o : kt; }
+        { const int32_t o = dpp_mov<DPP_BCAST15, 0xA>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_BCAST31, 0xC>(INT32_MIN, kt); kt = o > kt ? o : kt; }
+        const int32_t rt = from_prev_lane(kt, INT32_MIN);             // exclusive: lanes before this one
+        const uint32_t w = 63u - ((uint32_t)rt & 63u);                // the lane whose chain arrives (if any lane is above)
+        const int32_t Ew = __builtin_amdgcn_ds_bpermute((int)(w << 2), E);
+        const int32_t first_pos = pos_x + 1 - 4 * (int32_t)gl_x;      // 1-based position of this lane's first row
+        // the row-0 opener: word GO1 at position 1, key go + ge - ge; it is the earliest opener: it wins ties
+        const bool seed = lane == 0 || (kb0 - ge) >= (rt >> 6);
+        const uint32_t wn = w + 1u;                                   // the winner's exit position = first row of the lane after it
+        const int32_t w_exit = 4 * (int32_t)(wn * gq + (wn < grem ? wn : grem)) + 1;
+        const int32_t dist = seed ? first_pos - 1 : first_pos - w_exit;
+        const int32_t base = seed ? GO1 : Ew;
+        int32_t sc = word_score(base) + ge * dist; sc = sc > -28000 ? sc : -28000;      // (a chain that low loses to the first opener below)
+        Iin = word_make(sc, word_len(base) + (uint32_t)dist);
+        // did it arrive by an extension?  Not if it is the opener of the row right above: row 0 for lane 0, or the previous
+        // lane's last row when that lane's own last step chose the opener
+        const int32_t ext_prev = from_prev_lane(exitext ? 1 : 0, 0);
+        extin = (lane == 0) ? 0u : ((!seed && w + 1u == (uint32_t)lane && ext_prev == 0) ? 0u : (uint32_t)TBB_IEXT);
+    };
     uint32_t ychunk = 0;
+    RPROF_DECL
     for (uint32_t j = 1; j <= n; ++j) {
         const bool lastcol = j == n;
+        RPROF(7)
         // ---- poll the team's granules of column j-1 (column 0 came from the host) --------------------------------------------------
         if (j > 1) {
             const uint32_t want = j - 1;
-            const gptr<unsigned long long> gb = xchg + (size_t)(want & 1u) * C;
-            const unsigned long long t0 = wall_clock64();
-            for (;;) {
+            int lane_p = lane; asm volatile("" : "+v"(lane_p));
+            // (scalar base + lane offset through the buffer descriptor: no 64-bit address per lane; sc1 = agent scope, as the
+            // atomic load it stands for, and "volatile": every round of the loop reads memory)
+            const uint32_t gso = (want & 1u) * C * 8u;
+            // (a spinning wave takes issue slots from the wave it shares its SIMD with, which is computing another read's column: the
+            // loop is kept to a load, a compare and a sleep; the clock is looked at once in 1024 rounds)
+            const uint32_t t0 = (uint32_t)wall_clock64();
+            for (uint32_t spins = 1;; ++spins) {
                 bool ok = true;
 #pragma unroll
                 for (int qq = 0; qq < NQ; ++qq) {
-                    const uint32_t k = (uint32_t)lane + 64u * qq;
-                    if (k < nact) { gv[qq] = __hip_atomic_load(gb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok &= (uint32_t)(gv[qq] >> 48) == want; }
+                    const uint32_t k = (uint32_t)lane_p + 64u * qq;
+                    if (k < nact) {
+                        const u32x2 g2 = __builtin_amdgcn_raw_buffer_load_b64(rxc, 8u * k, gso, AUX_SC1 | AUX_VOLATILE);
+                        gv[qq] = ((unsigned long long)g2.y << 32) | g2.x; ok &= (g2.y >> 16) == want;
+                    }
                 }
                 if (__all(ok)) break;
-                if (wall_clock64() - t0 > 400000000ull) { if (lane == 0) *V.err = 1; return; }      // 4 s at 100 MHz: a partner is not resident
-                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 1023u) == 0 && (uint32_t)wall_clock64() - t0 > 400000000u) { if (lane == 0) *V.err = 1; return; }      // 4 s at 100 MHz: a partner is not resident
+                __builtin_amdgcn_s_sleep(STITCH_POLL_SLEEP);
             }
             uint32_t best = 0;
 #pragma unroll
@@ -296,6 +375,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             const int32_t colmax = (int32_t)wave_max_u32(best);
             gmax = colmax > gmax ? colmax : gmax;
         }
+        RPROF(0)
         // the read's bases, 64 columns per (coalesced) load: lane l holds y[jb + l]
         if (((j - 1) & 63u) == 0) ychunk = (j - 1 + lane < n) ? (uint32_t)yseq[j - 1 + lane] : 0u;
         const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)ychunk, (int)((j - 1) & 63u)) & 0xFFu;
@@ -356,11 +436,10 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         uint32_t* const tb_lane = (uint32_t*)(s_wave + LDS_TB) + lane_x;
         uint16_t* const bs_lane = (uint16_t*)(s_wave + LDS_BS) + lane_x;
 
+        RPROF(1)
         // ---- pass 1: rows top to bottom = registers 4 gl - 1 .. 0 ------------------------------------------------------------------
         Col cx;
         cx.MW1 = MW + 1; cx.XW1 = XW + 1; cx.GE1 = GE1; cx.GO1 = GO1; cx.JSWm1 = JSW - 1; cx.q = q;
-        cx.Tup = CHAIN_JUNK_T;                                            // (stands in for the row above the lane's first row: see the scan)
-        cx.Iw = CHAIN_NONE;
         cx.dgm = 0; cx.pad = pad;
         cx.jfix = lane == 0 ? JSW1 - JSW : 0;
         cx.xw = xw_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];                 // the lane's first row is byte 3 of its top group
@@ -374,66 +453,51 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             tb_lane[(g) * 64] = tbw; }
         REP20(P1)
 #undef P1
+        RPROF(2)
+        // ---- pass 1b: the chain of the lane's own openers, merged into the lane's cells; its "extended" bits join the codes in LDS ---
+        Col2 cl;
+        cl.GE1 = GE1; cl.GO1 = GO1;
+        cl.Iw = CHAIN_NONE; cl.extn = 0u;                                 // nothing arrives at the lane's first row from the lane itself
+        cl.tbn = tb_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];
+#define P1B(g) if ((uint32_t)(g) < gl_x) { \
+            uint32_t tbw = cl.tbn; if ((g) > 0) cl.tbn = tb_lane[((g) > 0 ? (g) - 1 : 0) * 64]; \
+            const int32_t i3 = chain_row<4 * (g) + 3>(S[4 * (g) + 3], tbw, cl), i2 = chain_row<4 * (g) + 2>(S[4 * (g) + 2], tbw, cl); \
+            const int32_t i1 = chain_row<4 * (g) + 1>(S[4 * (g) + 1], tbw, cl), i0 = chain_row<4 * (g)>(S[4 * (g)], tbw, cl); \
+            /* the insertion can only change a cell if its score reaches the cell's (S >= 0, so a negative insertion never does) */ \
+            const bool m3 = word_score(i3) >= word_score((int32_t)S[4 * (g) + 3]), m2 = word_score(i2) >= word_score((int32_t)S[4 * (g) + 2]); \
+            const bool m1 = word_score(i1) >= word_score((int32_t)S[4 * (g) + 1]), m0 = word_score(i0) >= word_score((int32_t)S[4 * (g)]); \
+            if (__builtin_expect((__ballot(m3) | __ballot(m2) | __ballot(m1) | __ballot(m0)) != 0ull, 0)) { \
+                merge_row<4 * (g) + 3>(S[4 * (g) + 3], tbw, m3, i3, bs_lane); merge_row<4 * (g) + 2>(S[4 * (g) + 2], tbw, m2, i2, bs_lane); \
+                merge_row<4 * (g) + 1>(S[4 * (g) + 1], tbw, m1, i1, bs_lane); merge_row<4 * (g)>(S[4 * (g)], tbw, m0, i0, bs_lane); \
+            } \
+            tb_lane[(g) * 64] = tbw; }
+        REP20(P1B)
+#undef P1B
+        RPROF(3)
         // ---- the insertion chain across the lanes ------------------------------------------------------------------------------------
-        // E = the chain of the lane's own openers as it arrives BEHIND the lane's last row (row_pass1's last step ended there; the
-        // first row's stand-in opener has long lost against real ones).  What arrives at lane l's first row is the best E of the
+        // E = the chain of the lane's own openers as it arrives BEHIND the lane's last row (pass 1b's last step ended there).
+        // What arrives at lane l's first row is the best E of the
         // lanes above — or the opener of row 0 (S' = 0: word GO1 at row 1) — carried down: score + ge per row, length + 1 per row.
         // "Best" = largest score at a common position, earliest lane on ties (the extension wins ties, :321): a prefix maximum
         // of position-normalised keys with the lane as a tag, as in fill_local16.hip.
         int32_t Iin; uint32_t extin;
-        {
-            const int32_t Eext = cx.Iw + GE1, Eopen = cx.Tup + GO1;         // one more step: from the lane's last row to the row behind it
-            const bool exitext = word_score(Eext) >= word_score(Eopen);
-            const int32_t E = exitext ? Eext : Eopen;
-            const int32_t pos_exit = pos_x + 1;                           // 1-based position of the row behind this lane's last row
-            int32_t nk = word_score(E) - ge * pos_exit;
-            if (gl == 0) nk = SCAN_LOW;                                   // lanes without rows
-            int32_t kt = (int32_t)(((uint32_t)nk << 6) | (uint32_t)(63 - lane));
-            { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 1>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 2>(INT32_MIN, kt); kt = o > kt ? o : kt; }
-            { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 4>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_ROW_SHR0 | 8>(INT32_MIN, kt); kt = o > kt ? o : kt; }
-            { const int32_t o = dpp_mov<DPP_BCAST15, 0xA>(INT32_MIN, kt); kt = o > kt ? o : kt; } { const int32_t o = dpp_mov<DPP_BCAST31, 0xC>(INT32_MIN, kt); kt = o > kt ? o : kt; }
-            const int32_t rt = from_prev_lane(kt, INT32_MIN);             // exclusive: lanes before this one
-            const uint32_t w = 63u - ((uint32_t)rt & 63u);                // the lane whose chain arrives (if any lane is above)
-            const int32_t Ew = __builtin_amdgcn_ds_bpermute((int)(w << 2), E);
-            const int32_t first_pos = pos_x + 1 - 4 * (int32_t)gl_x;      // 1-based position of this lane's first row
-            // the row-0 opener: word GO1 at position 1, key go + ge - ge; it is the earliest opener: it wins ties
-            const bool seed = lane == 0 || (kb0 - ge) >= (rt >> 6);
-            const uint32_t wn = w + 1u;                                   // the winner's exit position = first row of the lane after it
-            const int32_t w_exit = 4 * (int32_t)(wn * gq + (wn < grem ? wn : grem)) + 1;
-            const int32_t dist = seed ? first_pos - 1 : first_pos - w_exit;
-            const int32_t base = seed ? GO1 : Ew;
-            int32_t sc = word_score(base) + ge * dist; sc = sc > -28000 ? sc : -28000;      // (a chain that low loses to the first opener below)
-            Iin = word_make(sc, word_len(base) + (uint32_t)dist);
-            // did it arrive by an extension?  Not if it is the opener of the row right above: row 0 for lane 0, or the previous
-            // lane's last row when that lane's own last step chose the opener
-            const int32_t ext_prev = from_prev_lane(exitext ? 1 : 0, 0);
-            extin = (lane == 0) ? 0u : ((!seed && w + 1u == (uint32_t)lane && ext_prev == 0) ? 0u : (uint32_t)TBB_IEXT);
-        }
+        chain_across_lanes(cl.Iw, cl.extn != 0u, pos_x, gl_x, Iin, extin);
 
-        // ---- pass 2: the chain's extended bits, the insertion merge, the last column's int32 arrays; per group the lane's running
-        // records, y-suffix records and the traceback dword ------------------------------------------------------------------------------
-        Col2 c2;
-        c2.MW = MW; c2.XW = XW; c2.JSW = JSW; c2.GE1 = GE1; c2.GO1 = GO1; c2.q = q;
-        c2.JSW1 = JSW1; c2.row1_idx = 4u * gtop - 1u; c2.lane0 = lane == 0;
-        c2.Iw = Iin; c2.extn = extin; c2.rg4 = rg4_x;
-        c2.tbn = tb_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];
-        c2.lastcol = (uint32_t)__builtin_amdgcn_readfirstlane(lastcol ? 1 : 0);
-        c2.rS = rS; c2.oSlen = oSlen; c2.oIval = oIval; c2.oIlen = oIlen;
+        RPROF(4)
+        // ---- pass 2: where the arriving chain is alive, its extended bits and its merge (row_alive); per group the lane's running
+        // records, y-suffix records and the traceback dword; in the last column also the int32 arrays the fix-up kernel reads -----------
         const __amdgpu_buffer_rsrc_t rtb = __builtin_amdgcn_make_buffer_rsrc(tb0 + (size_t)(j - 1) * Rtot, 0, 0x7FFFFFFF, RSRC_WORD3);
-        Recs R; R.bw = 0; R.xrow = 0xFFFFFFFFu; R.r1 = 0xFFFFFFFFu; R.len1 = 0;
+        Recs R; R.bw = 0; R.gw = 0; R.g1 = 0;
         const uint32_t ycol = n - j;
         uint32_t tbw0 = 0;                                               // group 0's traceback dword (row m's byte is in it)
         const bool mine = lane == mlane;
         // register k of group 0 holds a row below m (a row that takes part in the records) unless this is the lane of row m and
         // k <= pad (k < pad: no row at all; k == pad: row m itself)
-#define P2(g) if ((uint32_t)(g) < gl_x) { \
-            uint32_t tbw = c2.tbn; if ((g) > 0) c2.tbn = tb_lane[((g) > 0 ? (g) - 1 : 0) * 64]; \
-            row_pass2<4 * (g) + 3, CIRC>(S[4 * (g) + 3], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 3u < pad)); row_pass2<4 * (g) + 2, CIRC>(S[4 * (g) + 2], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 2u < pad)); \
-            row_pass2<4 * (g) + 1, CIRC>(S[4 * (g) + 1], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 1u < pad)); row_pass2<4 * (g), CIRC>(S[4 * (g)], tbw, c2, xw_lane, bs_lane, !((g) == 0 && mine && 0u < pad)); \
+#define P2TAIL(g) \
             const uint32_t t3 = ((g) == 0 && mine && 3u <= pad) ? 0u : S[4 * (g) + 3], t2 = ((g) == 0 && mine && 2u <= pad) ? 0u : S[4 * (g) + 2]; \
             const uint32_t t1 = ((g) == 0 && mine && 1u <= pad) ? 0u : S[4 * (g) + 1], t0 = ((g) == 0 && mine) ? 0u : S[4 * (g)]; \
-            group_records(R, t3, t2, t1, t0, rowbase + (nrows - 4u - 4u * (g))); \
             const uint32_t g4 = (t3 > t2 ? t3 : t2) > (t1 > t0 ? t1 : t0) ? (t3 > t2 ? t3 : t2) : (t1 > t0 ? t1 : t0); \
+            group_records(R, g4, (uint32_t)(g)); \
             if ((int32_t)g4 >= ythr) { \
                 const uint32_t vo = 8u * (uint32_t)lane_x; \
                 if ((int32_t)t3 >= ythr) { u32x2 rec; rec.x = t3; rec.y = ycol; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, vo, (4 * (g) + 3) * 512, 0); } \
@@ -442,31 +506,68 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                 if ((int32_t)t0 >= ythr) { u32x2 rec; rec.x = t0; rec.y = ycol; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, vo, (4 * (g)) * 512, 0); } \
             } \
             __builtin_amdgcn_raw_buffer_store_b32(tbw, rtb, 4u * (uint32_t)lane_x, (g) * 256, AUX_NT); \
-            if ((g) == 0) tbw0 = tbw; \
+            if ((g) == 0) tbw0 = tbw;
+        {
+            ColA ca;
+            ca.GE1 = GE1; ca.GO1 = GO1;
+            ca.X = Iin; ca.Sup = SUP_NONE; ca.xext = extin; ca.alive = true;
+            uint32_t tbn = tb_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];       // the traceback codes of the NEXT group (read from LDS a group ahead)
+#define P2(g) if ((uint32_t)(g) < gl_x) { \
+            uint32_t tbw = tbn; if ((g) > 0) tbn = tb_lane[((g) > 0 ? (g) - 1 : 0) * 64]; \
+            if (__ballot(ca.alive) != 0ull) { \
+                row_alive<4 * (g) + 3>(S[4 * (g) + 3], tbw, ca, bs_lane); row_alive<4 * (g) + 2>(S[4 * (g) + 2], tbw, ca, bs_lane); \
+                row_alive<4 * (g) + 1>(S[4 * (g) + 1], tbw, ca, bs_lane); row_alive<4 * (g)>(S[4 * (g)], tbw, ca, bs_lane); \
+            } \
+            P2TAIL(g) \
         }
-        REP20(P2)
+            REP20(P2)
 #undef P2
+        }
+#undef P2TAIL
 
+        RPROF(5)
         // ---- the contig's epilogue: wave reductions over rows < m, row m, the column arg-max granule --------------------------------
         {
             const uint32_t xw = wave_max_u32(R.bw);
-            const uint32_t xrow2 = wave_min_u32(R.bw == xw && R.xrow != 0xFFFFFFFFu ? R.xrow + 1u : 0xFFFFFFFFu);   // 1-based row
+            // the four words of group G of lane L as the records saw them (the registers of row m and of no row count as 0)
+            auto fetch4 = [&](const uint32_t G, const int L, uint32_t (&w)[4]) {
+                w[0] = w[1] = w[2] = w[3] = 0u;
+#define FETCH(g) if (G == (uint32_t)(g)) { w[3] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g) + 3], L); w[2] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g) + 2], L); \
+                                             w[1] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g) + 1], L); w[0] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g)], L); }
+                REP20(FETCH)
+#undef FETCH
+                if (G == 0u && L == mlane) { w[0] = 0u; if (pad >= 1u) w[1] = 0u; if (pad >= 2u) w[2] = 0u; if (pad >= 3u) w[3] = 0u; }
+            };
+            // 0-based row of register 4 G + k of lane L
+            auto row_of = [&](const uint32_t G, const uint32_t k, const uint32_t L) -> uint32_t {
+                const uint32_t glL = gq + (L < grem ? 1u : 0u), rbL = 4u * (L * gq + (L < grem ? L : grem));
+                return rbL + 4u * glL - 1u - (4u * G + k);
+            };
             XsRec xb_;
-            if (xrow2 == 0xFFFFFFFFu) {
-                // no lane recorded a row: either there is no row below m (seed stays MIN, len 0), or every S word is 0 and
-                // the first row took the running value (0 > MIN, :408-417)
-                if (m > 1) { xb_.v = 0; xb_.len = 0; xb_.row = 1; } else { xb_.v = MIN_SCORE; xb_.len = 0; xb_.row = 0; }
-            }
-            else { xb_.v = (int32_t)(xw >> 16); xb_.len = xw & 0xFFFFu; xb_.row = xrow2; }
-            // column arg-max over rows 0..m-1: the first row holding the largest score; row 0 holds S = 0
             CmRec cb_;
-            {
+            if (xw == 0u) {
+                // every S word below row m is 0: the first row takes the running value (0 > MIN, :408-417) — unless there is no row
+                if (m > 1) { xb_.v = 0; xb_.len = 0; xb_.row = 1; } else { xb_.v = MIN_SCORE; xb_.len = 0; xb_.row = 0; }
+                cb_.v = 0; cb_.row = 0; cb_.len = 0;
+            }
+            else {
+                // rows ascend with the lane and, inside a lane, from register 4 gl - 1 down to 0: the topmost holder is in the lowest
+                // lane, in the group that lane met it in first, in the highest register
+                uint32_t w[4];
+                const int Lw = (int)__builtin_ctzll(__ballot(R.bw == xw));
+                const uint32_t Gw = (uint32_t)__builtin_amdgcn_readlane((int)R.gw, Lw);
+                fetch4(Gw, Lw, w);
+                const uint32_t kw = w[3] == xw ? 3u : w[2] == xw ? 2u : w[1] == xw ? 1u : 0u;
+                xb_.v = (int32_t)(xw >> 16); xb_.len = xw & 0xFFFFu; xb_.row = row_of(Gw, kw, (uint32_t)Lw) + 1u;       // 1-based row
+                // column arg-max over rows 0..m-1: the first row holding the largest score; row 0 holds S = 0
                 const uint32_t smax = xw >> 16;
-                const uint32_t rr1 = wave_min_u32((R.bw >> 16) == smax && R.r1 != 0xFFFFFFFFu ? R.r1 + 1u : 0xFFFFFFFFu);
-                if (smax == 0u || rr1 == 0xFFFFFFFFu) { cb_.v = 0; cb_.row = 0; cb_.len = 0; }
+                if (smax == 0u) { cb_.v = 0; cb_.row = 0; cb_.len = 0; }
                 else {
-                    const unsigned long long who = __ballot(R.r1 != 0xFFFFFFFFu && R.r1 + 1u == rr1 && (R.bw >> 16) == smax);
-                    cb_.v = (int32_t)smax; cb_.row = rr1; cb_.len = (uint32_t)__builtin_amdgcn_readlane((int)R.len1, (int)__builtin_ctzll(who));
+                    const int L1 = (int)__builtin_ctzll(__ballot((R.bw >> 16) == smax));
+                    const uint32_t G1 = (uint32_t)__builtin_amdgcn_readlane((int)R.g1, L1);
+                    if (L1 != Lw || G1 != Gw) fetch4(G1, L1, w);
+                    const uint32_t k1 = (w[3] >> 16) == smax ? 3u : (w[2] >> 16) == smax ? 2u : (w[1] >> 16) == smax ? 1u : 0u;
+                    cb_.v = (int32_t)smax; cb_.row = row_of(G1, k1, (uint32_t)L1) + 1u; cb_.len = w[k1] & 0xFFFFu;
                 }
             }
             // ---- row m (:350-351 seeded selection, :406-447 for i == m): register `pad` of lane mlane --------------------------------
@@ -483,6 +584,15 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             if (rowm_run_wins(xb_.v, ownS, word_score(ownDG))) { Sm = xb_.v; Slm = xb_.len; mvm = MK_XSUF; }
             else { Sm = ownS; Slm = ownSl; mvm = ownMv; if (ownSl > xb_.len) { do_x_m = true; lx = 0; } }
             const uint32_t smw = (uint32_t)word_make(Sm, Slm);
+            // the column arg-max is complete: announce it before the column's remaining stores (the other waves wait for nothing else)
+            if (Sm > cb_.v) { cb_.v = Sm; cb_.row = m; cb_.len = Slm; }
+            if (lane == 0) {
+                const unsigned long long gran = ((unsigned long long)j << 48) | ((unsigned long long)(uint32_t)(cb_.v & 0xFFFF) << 32) | ((unsigned long long)((cb_.len + 1u) & 0xFFFFu) << 16) | (cb_.row & 0xFFFFu);
+                u32x2 g2; g2.x = (uint32_t)gran; g2.y = (uint32_t)(gran >> 32);
+                __builtin_amdgcn_raw_buffer_store_b64(g2, rxc, 0u, ((j & 1u) * C + kmine) * 8u, AUX_SC1 | AUX_VOLATILE);   // one aligned 8-byte write, agent scope
+            }
+            if (cb_.v > vrun) vrun = cb_.v;
+            rowm_xsuf = mvm == MK_XSUF; rowm_S = Sm; rowm_len = Slm;
             if (mine) { if (pad == 0) S[0] = smw; else if (pad == 1) S[1] = smw; else if (pad == 2) S[2] = smw; else S[3] = smw; }   // the register of row m takes the seeded result
             const uint32_t rmi = roff + m - 1;
             if (mine) {
@@ -492,20 +602,40 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                 if (Sm >= ybase) {
                     const uint32_t yi = pad * 64u + (uint32_t)lane;
                     bool upd = Slm > 0u;
-                    if (lastcol) { const int32_t sn_ = word_score((int32_t)yrec[roff + yi].x); upd = Sm > sn_ || (Sm == sn_ && Slm > rl); }
-                    if (upd) { u32x2 rec; rec.x = smw; rec.y = n - j; yrec[roff + yi] = rec; }
+                    if (lastcol) { const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(ryr, 8u * yi, 0, 0); const int32_t sn_ = word_score((int32_t)old.x); upd = Sm > sn_ || (Sm == sn_ && Slm > rl); }
+                    if (upd) { u32x2 rec; rec.x = smw; rec.y = n - j; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, 8u * yi, 0, 0); }
                 }
                 Lx[(size_t)c * (n + 1) + j] = lx;
             }
-            if (Sm > cb_.v) { cb_.v = Sm; cb_.row = m; cb_.len = Slm; }
-            if (cb_.v > vrun) vrun = cb_.v;
-            rowm_xsuf = mvm == MK_XSUF; rowm_S = Sm; rowm_len = Slm;
-            if (lane == 0) {
-                const unsigned long long gran = ((unsigned long long)j << 48) | ((unsigned long long)(uint32_t)(cb_.v & 0xFFFF) << 32) | ((unsigned long long)((cb_.len + 1u) & 0xFFFFu) << 16) | (cb_.row & 0xFFFFu);
-                __hip_atomic_store(xchg + (size_t)(j & 1u) * C + kmine, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
     }
+    // ---- column n's arrays for the fix-up kernel (single_contig_aligner.rs:453-555): the final words, and the insertion chain at
+    // every row — recomputed here from the final words (an opener taken from a merged cell gives the same chain, see above)
+    {
+        int lane_x = lane; uint32_t gl_x = gl; int32_t pos_x = pos1_0; asm volatile("" : "+v"(lane_x), "+v"(gl_x), "+v"(pos_x));
+        const uint32_t rg4_x = 4u * (roff + (uint32_t)pos_x - 1u);       // 4 x (linear row index of register 0's row)
+        const bool mine = lane == mlane;
+        int32_t L = CHAIN_NONE; bool lext = false;
+#define LASTA(g) if ((uint32_t)(g) < gl_x) { _Pragma("unroll") for (int k = 3; k >= 0; --k) { \
+            const int32_t ext = L + GE1, open = (int32_t)S[4 * (g) + k] + GO1; lext = word_score(ext) >= word_score(open); L = lext ? ext : open; } }
+        REP20(LASTA)
+#undef LASTA
+        int32_t I; uint32_t extin;
+        chain_across_lanes(L, lext, pos_x, gl_x, I, extin);
+#define LASTB(g) if ((uint32_t)(g) < gl_x) { _Pragma("unroll") for (int k = 3; k >= 0; --k) { \
+            if (!((g) == 0 && mine && (uint32_t)k < pad)) { \
+                const uint32_t vo = rg4_x - 4u * (4 * (g) + k); \
+                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score((int32_t)S[4 * (g) + k]), rS, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len((int32_t)S[4 * (g) + k]), rS, vo, oSlen, 0); \
+                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score(I), rS, vo, oIval, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len(I), rS, vo, oIlen, 0); \
+            } \
+            const int32_t ext = I + GE1, open = (int32_t)S[4 * (g) + k] + GO1; I = word_score(ext) >= word_score(open) ? ext : open; } }
+        REP20(LASTB)
+#undef LASTB
+    }
+#ifdef STITCH_PROFILE
+    RPROF(6)
+    if (lane == 0) { unsigned long long* const pf = (unsigned long long*)((uint8_t*)V.err + 16); for (int k = 0; k < 8; ++k) atomicAdd(pf + k, (unsigned long long)pf_sum[k]); atomicAdd(pf + 8, 1ull); }
+#endif
     // ---- unpack the y-suffix records of this wave's rows into the arrays the fix-up kernel reads (its own stores: no barrier) -------
 #pragma unroll 1
     for (uint32_t i = 0; i < nrows; ++i) {

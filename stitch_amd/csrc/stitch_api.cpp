@@ -401,6 +401,7 @@ constexpr uint32_t REGS_WAVES = 4;
 uint32_t regs_plan(const stitch_ctx& c, const Job& jb) {
     if (c.knobs.no_regs || c.regs_wg_per_cu <= 0 || !local16_ok(c, jb)) return 0;
     if (c.opts.gap_extend < -1024 || c.opts.gap_open + c.opts.gap_extend < -8000) return 0;      // (16-bit insertion-chain words, fill_regs.hip)
+    if (c.opts.gap_open > 0) return 0;                 // (an opener from an insertion-derived cell must not beat the extension: fill_regs.hip)
     uint64_t rows = 0;
     for (uint32_t a : jb.act) { if (c.al[a].m > fill_regs_rows_per_wave()) return 0; rows += c.al[a].m; }
     const uint64_t min_rows = c.knobs.regs_min_rows >= 0 ? (uint64_t)c.knobs.regs_min_rows : 2048u;
@@ -701,7 +702,18 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         HIP_TRY(hipEventElapsedTime(&ms, c.ev[1], c.ev[2])); c.tm.walk_ms += ms;
         if (c.knobs.debug) fprintf(stderr, "[stitch] launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms, fix-up + walk %.1f ms\n", nj, G, waves, ms_fill, ms);
         if (attempt == 0) { c.tm.launches += 1; c.tm.jobs += nj; }
-        if (c.knobs.profile_dump && fast) {
+        if (c.knobs.profile_dump && kind == 2u) {
+            // fill_regs.hip, -DSTITCH_PROFILE: cycle sums per section over the waves of a read
+            static const char* nm[8] = {"poll", "jump", "pass1", "pass1b", "scan", "pass2+tail", "epilogue(last: +loop end)", "loop-top"};
+            for (uint32_t q = 0; q < std::min(nj, 4u); ++q) {
+                unsigned long long pf[9]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[q].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
+                const double cols = (double)std::max<unsigned long long>(pf[8], 1) * (double)views[q].n;
+                fprintf(stderr, "[prof] read %u: %llu waves;", q, pf[8]);
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.0f", nm[k], (double)pf[k] / cols);
+                fprintf(stderr, " (counter ticks per column and wave)\n");
+            }
+        }
+        if (c.knobs.profile_dump && fast && kind != 2u) {
             unsigned long long pf[128]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[0].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
             unsigned long long t_first = ~0ull;
             std::vector<unsigned long long> t_end(nj);
