@@ -45,11 +45,13 @@ constexpr int AUX_VOLATILE = (int)0x80000000u; // compiler-side: never merged, h
 // In-kernel stamps (diagnostic build only, -DSTITCH_PROFILE): per-wave cycle sums of the column loop's sections, added up per read
 // in the debug area behind V.err.  Never enabled in the product build.
 #ifdef STITCH_PROFILE
-#define RPROF_DECL uint32_t pf_t = (uint32_t)__builtin_readcyclecounter(), pf_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RPROF_DECL uint32_t pf_t = (uint32_t)__builtin_readcyclecounter(), pf_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_cnt[2] = {0, 0};
 #define RPROF(k) { const uint32_t pf_n = (uint32_t)__builtin_readcyclecounter(); pf_sum[k] += pf_n - pf_t; pf_t = pf_n; }
+#define RCOUNT(k) pf_cnt[k] += 1u;
 #else
 #define RPROF_DECL
 #define RPROF(k)
+#define RCOUNT(k)
 #endif
 
 // per wave in LDS: NG x 64 words of bases (constant), NG x 64 words of traceback codes (pass 1 -> pass 2), RMAX x 64 scores of
@@ -158,10 +160,10 @@ __device__ __forceinline__ int32_t chain_row(const uint32_t Sreg, uint32_t& tbw,
 // and for a cell the test does not admit, row_phase_c_word changes nothing (c2 false, or the jump / the clip win again).
 // The score of best{diagonal, deletion} comes from LDS, where pass 1 parked it.
 template <int IDX>
-__device__ __forceinline__ void merge_row(uint32_t& Sreg, uint32_t& tbw, const bool m, const int32_t Iw, const uint16_t* bs_lane) {
+__device__ __forceinline__ void merge_row(uint32_t& Sreg, uint32_t& tbw, const unsigned long long m, const int32_t Iw, const uint16_t* bs_lane) {
     constexpr int k = IDX & 3;
     const int32_t bs = (int32_t)(int16_t)bs_lane[IDX * 64];
-    const unsigned long long c2 = __ballot(m && word_score(Iw) > bs);
+    const unsigned long long c2 = m & __ballot(word_score(Iw) > bs);
     const uint32_t ntb = (tbw & ~(7u << (8 * k))) | ((uint32_t)MK_INS << (8 * k));
     // (selected IN PLACE: the register allocator otherwise gives the merged value a register of its own and copies every row's
     // word there and back on the path that does not merge)
@@ -169,31 +171,40 @@ __device__ __forceinline__ void merge_row(uint32_t& Sreg, uint32_t& tbw, const b
     asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tbw) : "v"(ntb), "s"(c2));
 }
 
-// ---- pass 2, one row of a group in which the chain X that arrived at the lane's first row is still alive in some lane
+// ---- pass 2, one group in which the chain X that arrived at the lane's first row is still alive in some lane.  The lanes'
+// states are kept as masks in scalar registers (ballots), the selects take them as they are: no branch but the one for a merge,
+// and that once per group — the openers may be taken from the words as pass 1b left them: a cell that X changes, and a cell
+// whose score X reaches without changing it, both open below X's own extension.
 struct ColA {
     int32_t GE1, GO1;
-    int32_t X;                                 // the chain carried down to the current row
-    int32_t Sup;                               // final word of the row above (SUP_NONE above the lane's first row)
-    uint32_t xext;                             // TBB_IEXT if X got to the current row by an extension (the first row: from the scan)
-    bool alive;                                // no opener has strictly beaten X so far
+    int32_t X;                                 // the chain carried down to the group's first row
+    int32_t Sup;                               // word of the row above (SUP_NONE above the lane's first row)
+    uint32_t xext;                             // TBB_IEXT if X got to the group's first row by an extension (a lane's first row: from the scan)
+    unsigned long long alive;                  // lanes in which no opener has strictly beaten X so far
 };
-template <int IDX>
-__device__ __forceinline__ void row_alive(uint32_t& Sreg, uint32_t& tbw, ColA& c, const uint16_t* bs_lane) {
-    constexpr int k = IDX & 3;
-    const int32_t Xw = c.X;
-    const int32_t open = c.Sup + c.GO1;
-    c.alive = c.alive && !(word_score(open) > word_score(Xw));
-    const uint32_t bit = k == 3 ? c.xext : (uint32_t)TBB_IEXT;               // (a lane's first row is byte 3 of its top group)
-    tbw |= c.alive ? bit << (8 * k) : 0u;                                    // pass 1b left the bit of the lane's own chain: 0 in a first row
-    const bool mx = c.alive && word_score(Xw) >= word_score((int32_t)Sreg);
-    if (__builtin_expect(__ballot(mx) != 0ull, 0)) {
-        // X reaches the cell's score.  If it beats best{diagonal, deletion} the cell becomes X whatever pass 1b made of it; if
-        // it does not, the lane's own chain (score <= X's) did not either, and the cell is as pass 1 left it
-        merge_row<IDX>(Sreg, tbw, mx, Xw, bs_lane);
+__device__ __forceinline__ uint32_t select_lanes(const unsigned long long lanes, const uint32_t v) {      // v in the lanes of the mask, 0 elsewhere
+    uint32_t r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(lanes)); return r;
+}
+template <int G>
+__device__ __forceinline__ void group_alive(uint32_t& s3, uint32_t& s2, uint32_t& s1, uint32_t& s0, uint32_t& tbw, ColA& c, const uint16_t* bs_lane) {
+    const int32_t x3 = c.X, x2 = x3 + c.GE1, x1 = x2 + c.GE1, x0 = x1 + c.GE1;
+    const unsigned long long a3 = c.alive & ~__ballot(word_score(c.Sup + c.GO1) > word_score(x3));
+    const unsigned long long a2 = a3 & ~__ballot(word_score((int32_t)s3 + c.GO1) > word_score(x2));
+    const unsigned long long a1 = a2 & ~__ballot(word_score((int32_t)s2 + c.GO1) > word_score(x1));
+    const unsigned long long a0 = a1 & ~__ballot(word_score((int32_t)s1 + c.GO1) > word_score(x0));
+    // an alive X arrived by an extension (a lane's first row, byte 3 of its top group: as the scan says); pass 1b left the bit of
+    // the lane's own chain there: 0 in a first row
+    tbw |= select_lanes(a3, c.xext << 24) | select_lanes(a2, (uint32_t)TBB_IEXT << 16) | select_lanes(a1, (uint32_t)TBB_IEXT << 8) | select_lanes(a0, (uint32_t)TBB_IEXT);
+    // X reaches a cell's score: if it beats best{diagonal, deletion} the cell becomes X whatever pass 1b made of it; if it does
+    // not, the lane's own chain (score <= X's) did not either, and the cell is as pass 1 left it (merge_row)
+    const unsigned long long m3 = a3 & __ballot(word_score(x3) >= word_score((int32_t)s3)), m2 = a2 & __ballot(word_score(x2) >= word_score((int32_t)s2));
+    const unsigned long long m1 = a1 & __ballot(word_score(x1) >= word_score((int32_t)s1)), m0 = a0 & __ballot(word_score(x0) >= word_score((int32_t)s0));
+    c.Sup = (int32_t)s0;
+    if (__builtin_expect((m3 | m2 | m1 | m0) != 0ull, 0)) {
+        merge_row<4 * G + 3>(s3, tbw, m3, x3, bs_lane); merge_row<4 * G + 2>(s2, tbw, m2, x2, bs_lane);
+        merge_row<4 * G + 1>(s1, tbw, m1, x1, bs_lane); merge_row<4 * G>(s0, tbw, m0, x0, bs_lane);
     }
-    c.Sup = (int32_t)Sreg;
-    c.X = Xw + c.GE1;
-    if (k == 3) c.xext = (uint32_t)TBB_IEXT;
+    c.X = x0 + c.GE1; c.xext = (uint32_t)TBB_IEXT; c.alive = a0;
 }
 
 // the lane's running records over a contig's column (rows below m): the largest S word and the group of four rows that held it
@@ -466,9 +477,9 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             /* the insertion can only change a cell if its score reaches the cell's (S >= 0, so a negative insertion never does) */ \
             const bool m3 = word_score(i3) >= word_score((int32_t)S[4 * (g) + 3]), m2 = word_score(i2) >= word_score((int32_t)S[4 * (g) + 2]); \
             const bool m1 = word_score(i1) >= word_score((int32_t)S[4 * (g) + 1]), m0 = word_score(i0) >= word_score((int32_t)S[4 * (g)]); \
-            if (__builtin_expect((__ballot(m3) | __ballot(m2) | __ballot(m1) | __ballot(m0)) != 0ull, 0)) { \
-                merge_row<4 * (g) + 3>(S[4 * (g) + 3], tbw, m3, i3, bs_lane); merge_row<4 * (g) + 2>(S[4 * (g) + 2], tbw, m2, i2, bs_lane); \
-                merge_row<4 * (g) + 1>(S[4 * (g) + 1], tbw, m1, i1, bs_lane); merge_row<4 * (g)>(S[4 * (g)], tbw, m0, i0, bs_lane); \
+            if (__builtin_expect((__ballot(m3) | __ballot(m2) | __ballot(m1) | __ballot(m0)) != 0ull, 0)) { RCOUNT(0) \
+                merge_row<4 * (g) + 3>(S[4 * (g) + 3], tbw, __ballot(m3), i3, bs_lane); merge_row<4 * (g) + 2>(S[4 * (g) + 2], tbw, __ballot(m2), i2, bs_lane); \
+                merge_row<4 * (g) + 1>(S[4 * (g) + 1], tbw, __ballot(m1), i1, bs_lane); merge_row<4 * (g)>(S[4 * (g)], tbw, __ballot(m0), i0, bs_lane); \
             } \
             tb_lane[(g) * 64] = tbw; }
         REP20(P1B)
@@ -498,28 +509,28 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             const uint32_t t1 = ((g) == 0 && mine && 1u <= pad) ? 0u : S[4 * (g) + 1], t0 = ((g) == 0 && mine) ? 0u : S[4 * (g)]; \
             const uint32_t g4 = (t3 > t2 ? t3 : t2) > (t1 > t0 ? t1 : t0) ? (t3 > t2 ? t3 : t2) : (t1 > t0 ? t1 : t0); \
             group_records(R, g4, (uint32_t)(g)); \
-            if ((int32_t)g4 >= ythr) { \
+            if ((int32_t)g4 >= ythr) {                       /* (two dword stores: a 64-bit one wants a register PAIR, i.e. a neighbour of the row's register saved and restored) */ \
                 const uint32_t vo = 8u * (uint32_t)lane_x; \
-                if ((int32_t)t3 >= ythr) { u32x2 rec; rec.x = t3; rec.y = ycol; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, vo, (4 * (g) + 3) * 512, 0); } \
-                if ((int32_t)t2 >= ythr) { u32x2 rec; rec.x = t2; rec.y = ycol; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, vo, (4 * (g) + 2) * 512, 0); } \
-                if ((int32_t)t1 >= ythr) { u32x2 rec; rec.x = t1; rec.y = ycol; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, vo, (4 * (g) + 1) * 512, 0); } \
-                if ((int32_t)t0 >= ythr) { u32x2 rec; rec.x = t0; rec.y = ycol; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, vo, (4 * (g)) * 512, 0); } \
+                if ((int32_t)t3 >= ythr) { __builtin_amdgcn_raw_buffer_store_b32(t3, ryr, vo, (4 * (g) + 3) * 512, 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (4 * (g) + 3) * 512 + 4, 0); } \
+                if ((int32_t)t2 >= ythr) { __builtin_amdgcn_raw_buffer_store_b32(t2, ryr, vo, (4 * (g) + 2) * 512, 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (4 * (g) + 2) * 512 + 4, 0); } \
+                if ((int32_t)t1 >= ythr) { __builtin_amdgcn_raw_buffer_store_b32(t1, ryr, vo, (4 * (g) + 1) * 512, 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (4 * (g) + 1) * 512 + 4, 0); } \
+                if ((int32_t)t0 >= ythr) { __builtin_amdgcn_raw_buffer_store_b32(t0, ryr, vo, (4 * (g)) * 512, 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (4 * (g)) * 512 + 4, 0); } \
             } \
             __builtin_amdgcn_raw_buffer_store_b32(tbw, rtb, 4u * (uint32_t)lane_x, (g) * 256, AUX_NT); \
             if ((g) == 0) tbw0 = tbw;
         {
             ColA ca;
             ca.GE1 = GE1; ca.GO1 = GO1;
-            ca.X = Iin; ca.Sup = SUP_NONE; ca.xext = extin; ca.alive = true;
+            ca.X = Iin; ca.Sup = SUP_NONE; ca.xext = extin; ca.alive = ~0ull;
             uint32_t tbn = tb_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];       // the traceback codes of the NEXT group (read from LDS a group ahead)
 #define P2(g) if ((uint32_t)(g) < gl_x) { \
             uint32_t tbw = tbn; if ((g) > 0) tbn = tb_lane[((g) > 0 ? (g) - 1 : 0) * 64]; \
-            if (__ballot(ca.alive) != 0ull) { \
-                row_alive<4 * (g) + 3>(S[4 * (g) + 3], tbw, ca, bs_lane); row_alive<4 * (g) + 2>(S[4 * (g) + 2], tbw, ca, bs_lane); \
-                row_alive<4 * (g) + 1>(S[4 * (g) + 1], tbw, ca, bs_lane); row_alive<4 * (g)>(S[4 * (g)], tbw, ca, bs_lane); \
-            } \
+            if ((ca.alive & __ballot(true)) != 0ull) { RCOUNT(1) } \
+            if ((ca.alive & __ballot(true)) != 0ull) group_alive<(g)>(S[4 * (g) + 3], S[4 * (g) + 2], S[4 * (g) + 1], S[4 * (g)], tbw, ca, bs_lane); \
             P2TAIL(g) \
-        }
+        } \
+        /* (assigned under a per-lane condition, the mask is a per-lane variable to the compiler: lane 0 is in every group) */ \
+        ca.alive = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ca.alive >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ca.alive);
             REP20(P2)
 #undef P2
         }
@@ -634,7 +645,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     }
 #ifdef STITCH_PROFILE
     RPROF(6)
-    if (lane == 0) { unsigned long long* const pf = (unsigned long long*)((uint8_t*)V.err + 16); for (int k = 0; k < 8; ++k) atomicAdd(pf + k, (unsigned long long)pf_sum[k]); atomicAdd(pf + 8, 1ull); }
+    if (lane == 0) { unsigned long long* const pf = (unsigned long long*)((uint8_t*)V.err + 16); for (int k = 0; k < 8; ++k) atomicAdd(pf + k, (unsigned long long)pf_sum[k]); atomicAdd(pf + 8, 1ull); atomicAdd(pf + 9, (unsigned long long)pf_cnt[0]); atomicAdd(pf + 10, (unsigned long long)pf_cnt[1]); }
 #endif
     // ---- unpack the y-suffix records of this wave's rows into the arrays the fix-up kernel reads (its own stores: no barrier) -------
 #pragma unroll 1

@@ -706,11 +706,11 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             // fill_regs.hip, -DSTITCH_PROFILE: cycle sums per section over the waves of a read
             static const char* nm[8] = {"poll", "jump", "pass1", "pass1b", "scan", "pass2+tail", "epilogue(last: +loop end)", "loop-top"};
             for (uint32_t q = 0; q < std::min(nj, 4u); ++q) {
-                unsigned long long pf[9]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[q].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
+                unsigned long long pf[11]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[q].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
                 const double cols = (double)std::max<unsigned long long>(pf[8], 1) * (double)views[q].n;
                 fprintf(stderr, "[prof] read %u: %llu waves;", q, pf[8]);
                 for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.0f", nm[k], (double)pf[k] / cols);
-                fprintf(stderr, " (counter ticks per column and wave)\n");
+                fprintf(stderr, " (counter ticks per column and wave); groups with a merge in pass 1b %.2f, groups visited by pass 2 %.2f per column and wave\n", (double)pf[9] / cols, (double)pf[10] / cols);
             }
         }
         if (c.knobs.profile_dump && fast && kind != 2u) {

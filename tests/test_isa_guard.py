@@ -24,6 +24,10 @@ def compile_asm(src, tmp_path, *defs):
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, src), "-o", out] + list(defs)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
+    # (-S does not run the assembler: an operand an inline asm statement cannot take only shows when the listing is assembled)
+    a = subprocess.run([os.path.join(os.path.dirname(HIPCC), "..", "lib", "llvm", "bin", "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", out, "-o", out + ".o"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert a.returncode == 0, a.stdout[-3000:]
     return open(out).read(), r.stdout
 
 
