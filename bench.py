@@ -33,8 +33,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SHADER_CLOCK_HZ = 2.4e9    # MI355X_MICROARCH.md "Chip-level parameters": max clock 2400 MHz
-# MI355X_MICROARCH.md "Wave scheduling": 4 SIMD-32 per CU, a wave64 VALU instruction issues over 2 cycles
-VALU_CYCLES_PER_WAVE_INST = 2.0
+# Integer VALU issue: one wave64 add / max / compare / select per 4 cycles and SIMD, however many waves the SIMD holds —
+# measured on this chip (profiles/ubench/valu_issue.hip -> valu_issue_mi355x.txt: 4.1-4.4 cycles with 2-4 waves, 4.9 with one).
+# MI355X_MICROARCH.md's 2 cycles (SIMD-32) is the v_fma_f32 figure; the integer instructions of the fill do not get it.
+VALU_CYCLES_PER_WAVE_INST = 4.0
 FILL_KERNELS = {0: "stitch::fill_kernel", 1: "stitch::fill_local16_kernel", 2: "stitch::fill_regs_kernel"}      # stitch_timing.fill_kind
 KERNEL_SOURCES = ("fill_local16.hip", "fill_regs.hip", "dp_core.h", "walk_core.h", "stitch_api.cpp")
 
@@ -199,12 +201,14 @@ def main():
                 bpc = (2.0 * k["FETCH_SIZE"]["avg_per_launch_raw"] + k["WRITE_SIZE"]["avg_per_launch_raw"]) * 1024.0 / cpl
                 out["roofline"]["traffic"] = bpc * cells / max(1, launches)
                 out["roofline"]["traffic_bytes_per_cell"] = bpc
-                # second view, as SURVEY.md 8(d) asks: integer VALU issue against 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction
+                # the bound that binds ("What bounds the fill"): integer VALU issue, against CUs x 4 SIMDs x 2.4 GHz / 4 cycles
+                # per wave64 instruction.  The peak is priced at the nominal clock; under this kernel the chip runs slower.
                 vpc = k["SQ_INSTS_VALU"]["avg_per_launch_raw"] * 64.0 / cpl
                 peak = prop.multi_processor_count * 4 * SHADER_CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST
                 out["roofline"]["valu"] = {"wave_insts_per_64_cells": vpc, "achieved_wave_insts_per_s": vpc * (cells / 64.0) / fill_s,
                                            "peak_wave_insts_per_s": peak, "frac": vpc * (cells / 64.0) / fill_s / peak,
-                                           "peak_source": "MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction issues over 2 cycles"}
+                                           "peak_source": "CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 integer instruction (measured: profiles/ubench/valu_issue_mi355x.txt)"}
+                out["roofline"]["binding"] = "valu_issue"
                 if "SQ_WAVE_CYCLES" in k and "SQ_WAIT_ANY" in k:
                     wc = k["SQ_WAVE_CYCLES"]["avg_per_launch_raw"]
                     out["roofline"]["wave_time_split"] = {n_: k[c_]["avg_per_launch_raw"] / wc for n_, c_ in
