@@ -293,3 +293,16 @@ def test_batch_split_invariance_and_determinism(monkeypatch):
     c = [[c.key() for c in ch] for ch, _ in al2.align(reads)]
     assert a == c
     assert al2.timing()["launches"] > 1
+
+
+def test_more_tiles_than_one_workgroup_slot_table_holds():
+    """A database of 128 x 10 kb contigs on both strands = 256 aligners x 40 tiles = 10 240 tiles of the streaming Local
+    kernel (contigs beyond 5120 rows: the register kernel does not take them).  ceil(tiles / 2048) = 5 workgroups per read
+    would leave one workgroup with 52 contigs = 2080 tiles, more than its slot table holds (2048): the host has to give the
+    read more workgroups (or fewer reads per launch), never cut tiles off.  Short reads keep the oracle's matrix small."""
+    rng = random.Random(77)
+    targets = [(f"big{k}", rand_seq(rng, 10000)) for k in range(128)]
+    reads = [chimera(rng, targets[:40], 60, err=0.03, both=True) for _ in range(3)]
+    al = run_pair(targets, reads, double_strand=True, check_sam=False)
+    tm = al.timing()
+    assert tm["fill_kind"] == 1 and tm["wg_per_read"] >= 6 and tm["fallbacks"] == 0, tm
