@@ -88,24 +88,27 @@ struct Col {
     int32_t MW1, XW1, GE1, GO1, JSWm1;         // (match, mismatch) << 16 | 1; gap words; the column's jump word minus one length unit
     uint32_t q;                                // y[j-1]
     int32_t aw1, DG;                           // the current row's (match | mismatch) word and diagonal candidate: old S word of the row above + aw1
-    uint32_t xw, xwn;                          // four bases: the group of the NEXT row; the group below it (read from LDS a group ahead)
     int32_t dgm; uint32_t pad;                 // row m (register `pad` of its lane): its diagonal candidate, needed for its finalisation
     int32_t jfix;                              // circular contigs: what row 1's jump word has over the column's (lane 0, consumed by its first row)
 };
 
 // ---- pass 1, one row (register IDX): everything of the cell that needs column j-1 only (dp_core.h row_phase_a_word), written
 // in place; the score of best{diagonal, deletion} is parked in LDS for the insertion merges
+// xcur = the four bases of the row's own group, xnext = those of the group below it, read from LDS at the group's first row.  The
+// two change roles from group to group (the caller passes them by the group's parity): no copy when a group ends.
+// The x-prefix clip (:383-389: a negative cell becomes score 0, length 0, move MK_XPRE) is NOT applied here: when the column's
+// jump word plus a mismatch is not negative, no cell of the column is (every cell can take the jump) — nearly every column of a
+// read that aligns at all.  In the other columns clip_row repairs a group's four cells behind its rows (one scalar branch per group).
 template <int IDX, bool CIRC>
-__device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32_t& tbw, Col& c, const uint32_t* xw_lane, uint16_t* bs_lane) {
+__device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32_t& tbw, Col& c, const uint32_t xcur, uint32_t& xnext, const uint32_t* xw_lane, uint16_t* bs_lane) {
     constexpr int k = IDX & 3;
     const int32_t aw1 = c.aw1, DG = c.DG;                    // prepared by the row above (or the column's prologue)
     const int32_t Sold = (int32_t)Sreg, Dold = (int32_t)Dreg;
     if (IDX > 0) {
         // the NEXT row's diagonal candidate takes this row's old S word: computed here, so that the old word is dead before the
         // new one is written and the row's S register is updated in place
-        if (k == 0) c.xw = c.xwn;                            // (read while the group above was computed: no LDS latency here)
-        if (k == 3 && IDX >= 7) c.xwn = xw_lane[((IDX >= 7 ? IDX - 7 : 0) >> 2) * 64];
-        const uint32_t xbn = (c.xw >> (8 * (k == 0 ? 3 : k - 1))) & 0xFFu;
+        if (k == 3 && IDX >= 7) xnext = xw_lane[((IDX >= 7 ? IDX - 7 : 0) >> 2) * 64];      // (used by the group's last row: no LDS latency there)
+        const uint32_t xbn = ((k == 0 ? xnext : xcur) >> (8 * (k == 0 ? 3 : k - 1))) & 0xFFu;
         c.aw1 = xbn == c.q ? c.MW1 : c.XW1;
         c.DG = Sold + c.aw1;                                 // diagonal: score + a, length + 1
     }
@@ -118,16 +121,24 @@ __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32
     int32_t JW = aw1 + c.JSWm1;
     if (CIRC && k == 3) { JW += c.jfix; c.jfix = 0; }       // (a lane's first row is byte 3 of its top group; only row 1 of the contig has a non-zero term)
     const bool c3 = JW > X;
-    int32_t T = c3 ? JW : bs2;
-    const bool c4 = T < 0;                                   // x-prefix clip: score 0, length 0
-    T = T > 0 ? T : 0;
-    const uint32_t code = (c4 ? MK_XPRE : c3 ? MK_JUMP : c1 ? MK_DEL : MK_DIAG) | (dext ? (uint32_t)TBB_DEXT : 0u);
+    const int32_t T = c3 ? JW : bs2;
+    const uint32_t code = (c3 ? MK_JUMP : c1 ? MK_DEL : MK_DIAG) | (dext ? (uint32_t)TBB_DEXT : 0u);
     tbw = k == 3 ? code : ((tbw << 8) | code);               // byte k of the group's dword: register 4g+3 first, 4g last
     bs_lane[IDX * 64] = (uint16_t)((uint32_t)bs2 >> 16);
     if (IDX < 4) { if (c.pad == (uint32_t)IDX) c.dgm = DG; }
     Sreg = (uint32_t)T; Dreg = (uint32_t)BD;
 }
 
+
+template <int IDX>
+__device__ __forceinline__ void clip_row(uint32_t& Sreg, uint32_t& tbw) {
+    constexpr int k = IDX & 3;
+    const unsigned long long c4 = __ballot((int32_t)Sreg < 0);
+    const uint32_t ntb = (tbw & ~(7u << (8 * k))) | ((uint32_t)MK_XPRE << (8 * k));
+    // (IN PLACE, as in merge_row)
+    asm("v_max_i32 %0, 0, %0" : "+v"(Sreg));
+    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(tbw) : "v"(ntb), "s"(c4));
+}
 
 // ---- pass 1b: the chain L of the lane's own openers.  chain_row steps it over one row (the chain arriving at the row is kept
 // for the merge, its "extended" bit goes into the group's traceback dword); merge_row merges a chain word into the cell where it
@@ -138,7 +149,6 @@ __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32
 // after the column loop rather than carry a test for the last column through every row of every column.)
 struct Col2 {
     int32_t GE1, GO1;
-    uint32_t tbn;                              // the traceback codes of the NEXT group (read from LDS a group ahead)
     int32_t Iw;                                // the insertion chain's word AT the current row ...
     uint32_t extn;                             // ... and TBB_IEXT if it got there by an extension (else 0)
 };
@@ -410,20 +420,33 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         };
         JumpInfo ji;
         {
-            unsigned long long ik = 0;
-#pragma unroll
-            for (int qq = 0; qq < NQ; ++qq) {
-                const uint32_t k = (uint32_t)lane + 64u * qq;
-                if (k < nact && k != kmine && (int32_t)k != kopp) {
-                    const unsigned long long key = ((gv[qq] & 0x0000FFFFFFFF0000ull) << 0) | (k + 1);      // score << 32 | len << 16 | k + 1
-                    ik = key > ik ? key : ik;
-                }
+            // the best OTHER contig (not this one, not its opposite strand): 0 = none, else its position in the active list + 1
+            uint32_t kbest1 = 0;
+            if (NQ == 1) {
+                // one record per lane: a 32-bit maximum of score << 16 | len, and the LAST lane that holds it
+                const bool elig = (uint32_t)lane < nact && (uint32_t)lane != kmine && lane != kopp;
+                const uint32_t key = elig ? (uint32_t)(gv[0] >> 16) : 0u;
+                const uint32_t mx = wave_max_u32(key);
+                const unsigned long long who = __ballot(elig && key == mx);
+                kbest1 = who ? 64u - (uint32_t)__builtin_clzll(who) : 0u;
             }
-            ik = wave_max_u64(ik);
+            else {
+                unsigned long long ik = 0;
+#pragma unroll
+                for (int qq = 0; qq < NQ; ++qq) {
+                    const uint32_t k = (uint32_t)lane + 64u * qq;
+                    if (k < nact && k != kmine && (int32_t)k != kopp) {
+                        const unsigned long long key = ((gv[qq] & 0x0000FFFFFFFF0000ull) << 0) | (k + 1);      // score << 32 | len << 16 | k + 1
+                        ik = key > ik ? key : ik;
+                    }
+                }
+                ik = wave_max_u64(ik);
+                kbest1 = (uint32_t)(ik & 0xFFFFu);
+            }
             { const unsigned long long b = rec_of(kmine); ji.score = (int32_t)((b >> 32) & 0xFFFFu) + jump_same; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = c; ji.from = (uint32_t)b & 0xFFFFu; }
             if (kopp >= 0) { const unsigned long long b = rec_of((uint32_t)kopp); const int32_t sc = (int32_t)((b >> 32) & 0xFFFFu) + jump_opp; if (sc > ji.score) { ji.score = sc; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = act_of((uint32_t)kopp); ji.from = (uint32_t)b & 0xFFFFu; } }
-            if (ik != 0) {
-                const uint32_t kw = (uint32_t)(ik & 0xFFFFu) - 1; const unsigned long long b = rec_of(kw);
+            if (kbest1 != 0) {
+                const uint32_t kw = kbest1 - 1; const unsigned long long b = rec_of(kw);
                 const int32_t sc = (int32_t)((b >> 32) & 0xFFFFu) + jump_inter;
                 if (sc > ji.score) { ji.score = sc; ji.len = (uint32_t)(b >> 16) & 0xFFFFu; ji.idx = act_of(kw); ji.from = (uint32_t)b & 0xFFFFu; }
             }
@@ -453,27 +476,35 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         cx.MW1 = MW + 1; cx.XW1 = XW + 1; cx.GE1 = GE1; cx.GO1 = GO1; cx.JSWm1 = JSW - 1; cx.q = q;
         cx.dgm = 0; cx.pad = pad;
         cx.jfix = lane == 0 ? JSW1 - JSW : 0;
-        cx.xw = xw_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];                 // the lane's first row is byte 3 of its top group
-        cx.xwn = xw_lane[(gl_x > 1 ? gl_x - 2 : 0) * 64];                // ... and the group below it
-        cx.aw1 = (cx.xw >> 24) == q ? cx.MW1 : cx.XW1;
+        uint32_t xwA = xw_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64], xwB = xwA;   // the lane's first row is byte 3 of its top group (whose parity differs between lanes: both copies)
+        cx.aw1 = (xwA >> 24) == q ? cx.MW1 : cx.XW1;
         // the row above a lane's first row is the previous lane's last row: register 0; row 0 for lane 0 (score 0, length 0 in Local mode)
         cx.DG = from_prev_lane((int)S[0], 0) + cx.aw1;
+#define XC(g) (((g) & 1) ? xwB : xwA)
+#define XN(g) (((g) & 1) ? xwA : xwB)
+        // (the smaller of the column's jump words, plus the worse of match and mismatch: a lower bound of every cell's jump candidate)
+        const int32_t jw_floor = (word_score(JSW1) < word_score(JSW) ? word_score(JSW1) : word_score(JSW)) + (P.mismatch < P.match ? P.mismatch : P.match);
+        const bool may_clip = __builtin_amdgcn_readfirstlane(jw_floor) < 0;
 #define P1(g) if ((uint32_t)(g) < gl_x) { uint32_t tbw; \
-            row_pass1<4 * (g) + 3, CIRC>(S[4 * (g) + 3], D[4 * (g) + 3], tbw, cx, xw_lane, bs_lane); row_pass1<4 * (g) + 2, CIRC>(S[4 * (g) + 2], D[4 * (g) + 2], tbw, cx, xw_lane, bs_lane); \
-            row_pass1<4 * (g) + 1, CIRC>(S[4 * (g) + 1], D[4 * (g) + 1], tbw, cx, xw_lane, bs_lane); row_pass1<4 * (g), CIRC>(S[4 * (g)], D[4 * (g)], tbw, cx, xw_lane, bs_lane); \
+            row_pass1<4 * (g) + 3, CIRC>(S[4 * (g) + 3], D[4 * (g) + 3], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); row_pass1<4 * (g) + 2, CIRC>(S[4 * (g) + 2], D[4 * (g) + 2], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); \
+            row_pass1<4 * (g) + 1, CIRC>(S[4 * (g) + 1], D[4 * (g) + 1], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); row_pass1<4 * (g), CIRC>(S[4 * (g)], D[4 * (g)], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); \
+            if (__builtin_expect(may_clip, 0)) { clip_row<4 * (g) + 3>(S[4 * (g) + 3], tbw); clip_row<4 * (g) + 2>(S[4 * (g) + 2], tbw); clip_row<4 * (g) + 1>(S[4 * (g) + 1], tbw); clip_row<4 * (g)>(S[4 * (g)], tbw); } \
             tb_lane[(g) * 64] = tbw; }
         REP20(P1)
 #undef P1
+#undef XC
+#undef XN
         RPROF(2)
         // ---- pass 1b: the chain of the lane's own openers, merged into the lane's cells; its "extended" bits join the codes in LDS ---
         Col2 cl;
         cl.GE1 = GE1; cl.GO1 = GO1;
         cl.Iw = CHAIN_NONE; cl.extn = 0u;                                 // nothing arrives at the lane's first row from the lane itself
-        cl.tbn = tb_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];
 #define P1B(g) if ((uint32_t)(g) < gl_x) { \
-            uint32_t tbw = cl.tbn; if ((g) > 0) cl.tbn = tb_lane[((g) > 0 ? (g) - 1 : 0) * 64]; \
-            const int32_t i3 = chain_row<4 * (g) + 3>(S[4 * (g) + 3], tbw, cl), i2 = chain_row<4 * (g) + 2>(S[4 * (g) + 2], tbw, cl); \
-            const int32_t i1 = chain_row<4 * (g) + 1>(S[4 * (g) + 1], tbw, cl), i0 = chain_row<4 * (g)>(S[4 * (g)], tbw, cl); \
+            const uint32_t tbl = tb_lane[(g) * 64];             /* (read here, used behind the four rows: no copy from group to group) */ \
+            uint32_t eb = 0u; \
+            const int32_t i3 = chain_row<4 * (g) + 3>(S[4 * (g) + 3], eb, cl), i2 = chain_row<4 * (g) + 2>(S[4 * (g) + 2], eb, cl); \
+            const int32_t i1 = chain_row<4 * (g) + 1>(S[4 * (g) + 1], eb, cl), i0 = chain_row<4 * (g)>(S[4 * (g)], eb, cl); \
+            uint32_t tbw = tbl | eb; \
             /* the insertion can only change a cell if its score reaches the cell's (S >= 0, so a negative insertion never does) */ \
             const bool m3 = word_score(i3) >= word_score((int32_t)S[4 * (g) + 3]), m2 = word_score(i2) >= word_score((int32_t)S[4 * (g) + 2]); \
             const bool m1 = word_score(i1) >= word_score((int32_t)S[4 * (g) + 1]), m0 = word_score(i0) >= word_score((int32_t)S[4 * (g)]); \
@@ -522,9 +553,8 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             ColA ca;
             ca.GE1 = GE1; ca.GO1 = GO1;
             ca.X = Iin; ca.Sup = SUP_NONE; ca.xext = extin; ca.alive = ~0ull;
-            uint32_t tbn = tb_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64];       // the traceback codes of the NEXT group (read from LDS a group ahead)
 #define P2(g) if ((uint32_t)(g) < gl_x) { \
-            uint32_t tbw = tbn; if ((g) > 0) tbn = tb_lane[((g) > 0 ? (g) - 1 : 0) * 64]; \
+            uint32_t tbw = tb_lane[(g) * 64]; \
             if ((ca.alive & __ballot(true)) != 0ull) { RCOUNT(1) } \
             if ((ca.alive & __ballot(true)) != 0ull) group_alive<(g)>(S[4 * (g) + 3], S[4 * (g) + 2], S[4 * (g) + 1], S[4 * (g)], tbw, ca, bs_lane); \
             P2TAIL(g) \
@@ -554,32 +584,27 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                 const uint32_t glL = gq + (L < grem ? 1u : 0u), rbL = 4u * (L * gq + (L < grem ? L : grem));
                 return rbL + 4u * glL - 1u - (4u * G + k);
             };
+            // The granule the other waves wait for needs the column arg-max (largest score, topmost row, its length) and row m; the
+            // x-suffix running maximum's ROW is only stored (Lx): it is looked up after the granule has gone out.
+            // rows ascend with the lane and, inside a lane, from register 4 gl - 1 down to 0: the topmost holder of a value is in the
+            // lowest lane that has it, in the group that lane met it in first, in the highest register
             XsRec xb_;
             CmRec cb_;
+            uint32_t w[4]; int L1 = -1; uint32_t G1 = 0;
+            const uint32_t smax = xw >> 16;
             if (xw == 0u) {
                 // every S word below row m is 0: the first row takes the running value (0 > MIN, :408-417) — unless there is no row
-                if (m > 1) { xb_.v = 0; xb_.len = 0; xb_.row = 1; } else { xb_.v = MIN_SCORE; xb_.len = 0; xb_.row = 0; }
-                cb_.v = 0; cb_.row = 0; cb_.len = 0;
+                if (m > 1) { xb_.v = 0; xb_.len = 0; } else { xb_.v = MIN_SCORE; xb_.len = 0; }
             }
+            else { xb_.v = (int32_t)smax; xb_.len = xw & 0xFFFFu; }
+            // column arg-max over rows 0..m-1: the first row holding the largest score; row 0 holds S = 0
+            if (smax == 0u) { cb_.v = 0; cb_.row = 0; cb_.len = 0; }
             else {
-                // rows ascend with the lane and, inside a lane, from register 4 gl - 1 down to 0: the topmost holder is in the lowest
-                // lane, in the group that lane met it in first, in the highest register
-                uint32_t w[4];
-                const int Lw = (int)__builtin_ctzll(__ballot(R.bw == xw));
-                const uint32_t Gw = (uint32_t)__builtin_amdgcn_readlane((int)R.gw, Lw);
-                fetch4(Gw, Lw, w);
-                const uint32_t kw = w[3] == xw ? 3u : w[2] == xw ? 2u : w[1] == xw ? 1u : 0u;
-                xb_.v = (int32_t)(xw >> 16); xb_.len = xw & 0xFFFFu; xb_.row = row_of(Gw, kw, (uint32_t)Lw) + 1u;       // 1-based row
-                // column arg-max over rows 0..m-1: the first row holding the largest score; row 0 holds S = 0
-                const uint32_t smax = xw >> 16;
-                if (smax == 0u) { cb_.v = 0; cb_.row = 0; cb_.len = 0; }
-                else {
-                    const int L1 = (int)__builtin_ctzll(__ballot((R.bw >> 16) == smax));
-                    const uint32_t G1 = (uint32_t)__builtin_amdgcn_readlane((int)R.g1, L1);
-                    if (L1 != Lw || G1 != Gw) fetch4(G1, L1, w);
-                    const uint32_t k1 = (w[3] >> 16) == smax ? 3u : (w[2] >> 16) == smax ? 2u : (w[1] >> 16) == smax ? 1u : 0u;
-                    cb_.v = (int32_t)smax; cb_.row = row_of(G1, k1, (uint32_t)L1) + 1u; cb_.len = w[k1] & 0xFFFFu;
-                }
+                L1 = (int)__builtin_ctzll(__ballot((R.bw >> 16) == smax));
+                G1 = (uint32_t)__builtin_amdgcn_readlane((int)R.g1, L1);
+                fetch4(G1, L1, w);
+                const uint32_t k1 = (w[3] >> 16) == smax ? 3u : (w[2] >> 16) == smax ? 2u : (w[1] >> 16) == smax ? 1u : 0u;
+                cb_.v = (int32_t)smax; cb_.row = row_of(G1, k1, (uint32_t)L1) + 1u; cb_.len = w[k1] & 0xFFFFu;
             }
             // ---- row m (:350-351 seeded selection, :406-447 for i == m): register `pad` of lane mlane --------------------------------
             const uint32_t wm = pad == 0 ? S[0] : pad == 1 ? S[1] : pad == 2 ? S[2] : S[3];
@@ -589,26 +614,33 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             const int32_t ownDG = __builtin_amdgcn_readlane(dgm, mlane);
             const uint32_t ownByte = (uint32_t)__builtin_amdgcn_readlane((int)bytem, mlane);
             const int32_t ownS = word_score(ownW); const uint32_t ownMv = ownByte & 7u, ownSl = word_len(ownW);
-            int32_t Sm; uint32_t Slm, mvm, lx;
-            lx = xb_.row == 0 ? 0u : m - xb_.row;
+            int32_t Sm; uint32_t Slm, mvm;
             bool do_x_m = false;
             if (rowm_run_wins(xb_.v, ownS, word_score(ownDG))) { Sm = xb_.v; Slm = xb_.len; mvm = MK_XSUF; }
-            else { Sm = ownS; Slm = ownSl; mvm = ownMv; if (ownSl > xb_.len) { do_x_m = true; lx = 0; } }
+            else { Sm = ownS; Slm = ownSl; mvm = ownMv; if (ownSl > xb_.len) do_x_m = true; }
             const uint32_t smw = (uint32_t)word_make(Sm, Slm);
-            // the column arg-max is complete: announce it before the column's remaining stores (the other waves wait for nothing else)
+            // the column arg-max is complete: announce it before the column's remaining work (the other waves wait for nothing else)
             if (Sm > cb_.v) { cb_.v = Sm; cb_.row = m; cb_.len = Slm; }
             if (lane == 0) {
                 const unsigned long long gran = ((unsigned long long)j << 48) | ((unsigned long long)(uint32_t)(cb_.v & 0xFFFF) << 32) | ((unsigned long long)((cb_.len + 1u) & 0xFFFFu) << 16) | (cb_.row & 0xFFFFu);
                 u32x2 g2; g2.x = (uint32_t)gran; g2.y = (uint32_t)(gran >> 32);
                 __builtin_amdgcn_raw_buffer_store_b64(g2, rxc, 0u, ((j & 1u) * C + kmine) * 8u, AUX_SC1 | AUX_VOLATILE);   // one aligned 8-byte write, agent scope
             }
+            // the x-suffix running maximum's row (1-based; 0: none): the topmost row holding the largest WORD
+            if (xw == 0u) xb_.row = m > 1 ? 1u : 0u;
+            else {
+                const int Lw = (int)__builtin_ctzll(__ballot(R.bw == xw));
+                const uint32_t Gw = (uint32_t)__builtin_amdgcn_readlane((int)R.gw, Lw);
+                if (Lw != L1 || Gw != G1) fetch4(Gw, Lw, w);
+                const uint32_t kw = w[3] == xw ? 3u : w[2] == xw ? 2u : w[1] == xw ? 1u : 0u;
+                xb_.row = row_of(Gw, kw, (uint32_t)Lw) + 1u;
+            }
+            const uint32_t lx = (do_x_m || xb_.row == 0u) ? 0u : m - xb_.row;
             if (cb_.v > vrun) vrun = cb_.v;
             rowm_xsuf = mvm == MK_XSUF; rowm_S = Sm; rowm_len = Slm;
             if (mine) { if (pad == 0) S[0] = smw; else if (pad == 1) S[1] = smw; else if (pad == 2) S[2] = smw; else S[3] = smw; }   // the register of row m takes the seeded result
-            const uint32_t rmi = roff + m - 1;
             if (mine) {
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(mvm | (ownByte & (TBB_IEXT | TBB_DEXT))), rtb, 4u * (uint32_t)lane + pad, 0, 0);
-                if (lastcol) { V.S[rmi] = Sm; V.Slen[rmi] = Slm; }
                 const uint32_t rl = lastcol ? (do_x_m ? ownSl : xb_.len) : 0u;
                 if (Sm >= ybase) {
                     const uint32_t yi = pad * 64u + (uint32_t)lane;
