@@ -11,7 +11,7 @@ rep('#define P1(g) if ((uint32_t)(g) < gl_x) { uint32_t tbw; \\', '#define P1(g)
 rep('            tb_lane[(g) * 64] = tbw; }\n        REP20(P1)', '            tb_lane[(g) * 64] = tbw; asm volatile("; P1G_END"); }\n        REP20(P1)')
 rep('#define P1B(g) if ((uint32_t)(g) < gl_x) { \\', '#define P1B(g) if ((uint32_t)(g) < gl_x) { asm volatile("; P1BG_BEGIN"); \\')
 rep('            tb_lane[(g) * 64] = tbw; }\n        REP20(P1B)', '            tb_lane[(g) * 64] = tbw; asm volatile("; P1BG_END"); }\n        REP20(P1B)')
-rep('            P2TAIL(g) \\\n        }\n            REP20(P2)', '            asm volatile("; TAIL_BEGIN"); P2TAIL(g) asm volatile("; TAIL_END"); \\\n        }\n            REP20(P2)')
+rep('            P2TAIL(g) \\\n        } \\', '            asm volatile("; TAIL_BEGIN"); P2TAIL(g) asm volatile("; TAIL_END"); \\\n        } \\')
 tmp = os.path.join(root, 'stitch_amd/csrc/_m.hip')
 open(tmp, 'w').write(s)
 try:
@@ -26,6 +26,6 @@ for tag in ['P1G', 'P1BG', 'TAIL']:
         if '; %s_BEGIN' % tag in L[i]:
             j = i
             while '; %s_END' % tag not in L[j] and j < end: j += 1
-            res.append((sum(1 for l in L[i:j] if re.match(r'\s+v_', l)), sum(1 for l in L[i:j] if re.match(r'\s+s_', l)), sum(1 for l in L[i:j] if 's_cbranch' in l))); i = j
+            res.append((sum(1 for l in L[i:j] if re.match(r'\s+v_', l)), sum(1 for l in L[i:j] if re.match(r'\s+s_', l)), sum(1 for l in L[i:j] if 's_cbranch' in l), sum(1 for l in L[i:j] if 'v_mov_b32' in l))); i = j
         i += 1
-    print(tag, len(res), '(valu, salu, branches) per group:', res[:10])
+    print(tag, len(res), '(valu, salu, branches, v_mov) per group:', res[:10])
