@@ -18,25 +18,47 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+# per-file compiler flags.  fill_regs.hip: its sweeps are long straight-line blocks of compare -> select pairs, and gfx950 wants two
+# wait states between a vector compare's scalar result and the vector instruction that reads it; the default scheduler leaves ~300
+# s_nop in the column loop, the ILP scheduler ~90 (each an issue slot of a wave that is short of them: -2 % launch time, measured).
+FILE_FLAGS = {"fill_regs.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + \
-          [os.path.join(CSRC, f) for f in SOURCES]
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
     for d in os.environ.get("STITCH_DEFINES", "").split():
-        cmd.append("-D" + d)                    # experiments only
-    cmd += os.environ.get("STITCH_HIPCC_FLAGS", "").split()          # experiments only
+        common.append("-D" + d)                 # experiments only
+    common += os.environ.get("STITCH_HIPCC_FLAGS", "").split()       # experiments only
     if os.environ.get("STITCH_PROFILE_BUILD"):
-        cmd.append("-DSTITCH_PROFILE")          # diagnostic build with in-kernel stamps (never shipped)
+        common.append("-DSTITCH_PROFILE")       # diagnostic build with in-kernel stamps (never shipped)
     if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        common.append("-Rpass-analysis=kernel-resource-usage")
+    # one object per source (compiled side by side), then the link
+    objdir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for f in SOURCES:
+        obj = os.path.join(objdir, f + ".o")
+        cmd = common + FILE_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", obj]
+        procs.append((f, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    out, failed = "", []
+    for f, obj, pr in procs:
+        o, _ = pr.communicate()
+        out += o
+        if pr.returncode != 0:
+            failed.append(f)
+    if failed:
+        raise RuntimeError("hipcc failed on " + ", ".join(failed) + ":\n" + out)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + [obj for _, obj, _ in procs],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout)
+        raise RuntimeError("linking libstitch_amd.so failed:\n" + r.stdout)
     if verbose:
-        print(r.stdout)
+        print(out)
     return LIB_PATH
 
 

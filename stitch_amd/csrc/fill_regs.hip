@@ -9,9 +9,10 @@
 //   * One insertion scan per CONTIG and column instead of one per 256-row tile: the chain I[i] = max(I[i-1]+ge, S'[i-1]+go+ge)
 //     runs serially down a lane's rows (a compare and two selects per row) and crosses lanes once, as a lane-tagged DPP prefix
 //     maximum.  The per-tile overheads of the tiled kernels (scan, reductions, slot bookkeeping) go.
-//   * Registers 4g+3 .. 4g of a lane = four consecutive rows ("group" g), top to bottom; a lane's rows end at register 0, so the
-//     value the NEXT lane needs is always in register 0.  The contig's ceil(m / 4) groups are dealt to the lanes as evenly as
-//     possible (the first lanes hold one group more); the unrolled code of a group runs under `g < groups of this lane`.
+//   * Registers 4g+3 .. 4g of a lane = four consecutive rows ("group" g), top to bottom.  The contig's ceil(m / 4) groups are
+//     dealt to the lanes as evenly as possible: the first lanes hold one group more than the others, and EVERY lane's first row
+//     is in the fullest lane's top register — a lane with a group less ends in register 4, group 0 is not its own.  So the
+//     unrolled code of the groups g >= 1 runs under a scalar condition and with every lane enabled; only group 0 is per lane.
 //   * A read's contigs are dealt to the waves of G workgroups (a team); per column the team exchanges the per-contig column
 //     arg-max (the next column's jump sources, get_jump_info :677-697) through one 8-byte granule {column, score, len, from} per
 //     contig and column parity, written by the wave that owns the contig and polled by every wave on its own: there is no
@@ -125,7 +126,7 @@ __device__ __forceinline__ void row_pass1(uint32_t& Sreg, uint32_t& Dreg, uint32
     const uint32_t code = (c3 ? MK_JUMP : c1 ? MK_DEL : MK_DIAG) | (dext ? (uint32_t)TBB_DEXT : 0u);
     tbw = k == 3 ? code : ((tbw << 8) | code);               // byte k of the group's dword: register 4g+3 first, 4g last
     bs_lane[IDX * 64] = (uint16_t)((uint32_t)bs2 >> 16);
-    if (IDX < 4) { if (c.pad == (uint32_t)IDX) c.dgm = DG; }
+    if (IDX < 8) { if (c.pad == (uint32_t)IDX) c.dgm = DG; }           // (c.pad: the register of row m, one of the first eight)
     Sreg = (uint32_t)T; Dreg = (uint32_t)BD;
 }
 
@@ -267,8 +268,15 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     const uint32_t nrows = 4 * gl;
     const uint32_t rowbase = 4 * ((uint32_t)lane * gq + ((uint32_t)lane < grem ? (uint32_t)lane : grem));   // 0-based row of the lane's first row
     const uint32_t pad = 4 * ngr - m;                 // 0..3 registers without a row, at the bottom of the last lane that has rows
-    const int mlane = (int)(gq > 0 ? 63u : grem - 1u);            // row m: register `pad` of that lane
+    const int mlane = (int)(gq > 0 ? 63u : grem - 1u);            // row m: register rsh + `pad` of that lane
     const uint32_t gtop = gq + (grem > 0 ? 1u : 0u);  // groups of the fullest lane: the unrolled blocks g >= gtop are skipped by every lane
+    // EVERY lane's first row sits in register 4 gtop - 1: the lanes that hold one group less than the fullest have it at the
+    // BOTTOM — their rows end in register 4 (rsh), group 0 is not theirs.  So the group blocks g >= 1 run under a scalar condition
+    // (g < gtop) and only group 0 is per lane.
+    const uint32_t rsh = (grem > 0 && (uint32_t)lane >= grem) ? 4u : 0u;          // register of the lane's last row
+    const bool has0 = gl > 0 && rsh == 0u;                                        // group 0 is this lane's
+    const uint32_t gm = (grem > 0 && gq > 0) ? 1u : 0u;                           // group of row m (of lane mlane): its register is 4 gm + pad
+    const uint32_t padreg = 4u * gm + pad;
     const int32_t jump_same = P.jump_same, jump_opp = P.jump_opp, jump_inter = P.jump_inter;
     const int32_t MW = (int32_t)((uint32_t)P.match << 16), XW = (int32_t)((uint32_t)P.mismatch << 16);
     const int32_t GE1 = (int32_t)((uint32_t)P.gap_extend << 16) + 1, GO1 = (int32_t)((uint32_t)(P.gap_open + P.gap_extend) << 16) + 1;
@@ -279,8 +287,8 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     const gptr<uint32_t> jt_idx = as_global(V.jt_idx), jt_from = as_global(V.jt_from), Lx = as_global(V.Lx);
     uint8_t* const tb0 = V.tb + roff;
     const bool ymode_global = V.yrec_global != 0;
-    // register IDX of this lane holds the contig's row (1-based) pos1 = rowbase + nrows - IDX
-    const int32_t pos1_0 = (int32_t)(rowbase + nrows);                  // ... of register 0
+    // register IDX of this lane holds the contig's row (1-based) pos1 = rowbase + nrows - (IDX - rsh)
+    const int32_t pos1_0 = (int32_t)(rowbase + nrows);                  // ... of the lane's LAST row (register rsh)
     // scan terms of register IDX: key = S'.score + kbase + ge * IDX, q = S'.len + qbase + IDX with kbase = go + ge - ge * pos1_0, qbase = 1 - pos1_0;
     // I score = run.key + bbase - ge * IDX, I length = run.q + lbase - IDX with bbase = ge * pos1_0, lbase = pos1_0
 
@@ -290,10 +298,10 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     for (int i = 0; i < RMAX; ++i) { S[i] = 0u; D[i] = (uint32_t)word_make(-16384, 0); }     // D = "MIN": never extends, never wins, cannot wrap
     {
         uint32_t* const xw0 = (uint32_t*)(s_wave + LDS_XW) + lane;
-#define INIT(g) if ((uint32_t)(g) < gl) { \
+#define INIT(g) if ((g) == 0 ? has0 : (gl > 0 && (uint32_t)(g) < gtop)) { \
             uint32_t w = 0; \
             _Pragma("unroll") for (int k = 3; k >= 0; --k) { \
-                const uint32_t row = rowbase + (nrows - 1 - (4u * (g) + (uint32_t)k));                    /* 0-based row of the contig */ \
+                const uint32_t row = rowbase + (nrows - 1 - (4u * (g) + (uint32_t)k - rsh));              /* 0-based row of the contig */ \
                 uint32_t b = 0xFFu;                                                                         /* no row: equals no base */ \
                 if (row < m) { \
                     const uint32_t tr = cd.troff + row; \
@@ -361,6 +369,9 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         const int32_t ext_prev = from_prev_lane(exitext ? 1 : 0, 0);
         extin = (lane == 0) ? 0u : ((!seed && w + 1u == (uint32_t)lane && ext_prev == 0) ? 0u : (uint32_t)TBB_IEXT);
     };
+    // (the two words a row selects between by the base comparison, kept in vector registers: a select cannot take both from scalar
+    // registers, and re-materialising them costs two instructions per group of rows)
+    int32_t MW1v = MW + 1, XW1v = XW + 1; asm volatile("" : "+v"(MW1v), "+v"(XW1v));
     uint32_t ychunk = 0;
     RPROF_DECL
     for (uint32_t j = 1; j <= n; ++j) {
@@ -464,8 +475,8 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
 
         // (what depends only on the lane is constant over the read: the compiler would hoist the base words and the group guards out
         // of the column loop and pin registers for them; values it cannot see through keep them one LDS read / one compare each)
-        int lane_x = lane; uint32_t gl_x = gl; int32_t pos_x = pos1_0; asm volatile("" : "+v"(lane_x), "+v"(gl_x), "+v"(pos_x));
-        const uint32_t rg4_x = 4u * (roff + (uint32_t)pos_x - 1u);       // 4 x (linear row index of register 0's row)
+        const int lane_x = lane; uint32_t gl_x = gl; int32_t pos_x = pos1_0; bool has0_x = has0; asm volatile("" : "+v"(gl_x), "+v"(pos_x)); { uint32_t h = has0 ? 1u : 0u; asm volatile("" : "+v"(h)); has0_x = h != 0u; }
+        uint32_t gtop_x = gtop; asm volatile("" : "+s"(gtop_x));        // (opaque: the compiler would keep twenty compare results per sweep in scalar registers)
         const uint32_t* const xw_lane = (const uint32_t*)(s_wave + LDS_XW) + lane_x;
         uint32_t* const tb_lane = (uint32_t*)(s_wave + LDS_TB) + lane_x;
         uint16_t* const bs_lane = (uint16_t*)(s_wave + LDS_BS) + lane_x;
@@ -473,19 +484,20 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         RPROF(1)
         // ---- pass 1: rows top to bottom = registers 4 gl - 1 .. 0 ------------------------------------------------------------------
         Col cx;
-        cx.MW1 = MW + 1; cx.XW1 = XW + 1; cx.GE1 = GE1; cx.GO1 = GO1; cx.JSWm1 = JSW - 1; cx.q = q;
-        cx.dgm = 0; cx.pad = pad;
+        cx.MW1 = MW1v; cx.XW1 = XW1v; cx.GE1 = GE1; cx.GO1 = GO1; cx.JSWm1 = JSW - 1; cx.q = q;
+        cx.dgm = 0; cx.pad = padreg;
         cx.jfix = lane == 0 ? JSW1 - JSW : 0;
-        uint32_t xwA = xw_lane[(gl_x > 0 ? gl_x - 1 : 0) * 64], xwB = xwA;   // the lane's first row is byte 3 of its top group (whose parity differs between lanes: both copies)
+        uint32_t xwA = xw_lane[(gtop - 1u) * 64], xwB = xwA;             // every lane's first row is byte 3 of group gtop - 1 (either parity: both copies)
         cx.aw1 = (xwA >> 24) == q ? cx.MW1 : cx.XW1;
-        // the row above a lane's first row is the previous lane's last row: register 0; row 0 for lane 0 (score 0, length 0 in Local mode)
-        cx.DG = from_prev_lane((int)S[0], 0) + cx.aw1;
+        // the row above a lane's first row is the previous lane's last row: its register rsh; row 0 for lane 0 (score 0, length 0 in Local mode)
+        cx.DG = from_prev_lane((int)(rsh ? S[4] : S[0]), 0) + cx.aw1;
 #define XC(g) (((g) & 1) ? xwB : xwA)
 #define XN(g) (((g) & 1) ? xwA : xwB)
         // (the smaller of the column's jump words, plus the worse of match and mismatch: a lower bound of every cell's jump candidate)
         const int32_t jw_floor = (word_score(JSW1) < word_score(JSW) ? word_score(JSW1) : word_score(JSW)) + (P.mismatch < P.match ? P.mismatch : P.match);
         const bool may_clip = __builtin_amdgcn_readfirstlane(jw_floor) < 0;
-#define P1(g) if ((uint32_t)(g) < gl_x) { uint32_t tbw; \
+#define GUARD(g) ((g) == 0 ? has0_x : (uint32_t)(g) < gtop_x)    /* per lane for group 0 only; the other groups under a scalar condition */
+#define P1(g) if (GUARD(g)) { uint32_t tbw; \
             row_pass1<4 * (g) + 3, CIRC>(S[4 * (g) + 3], D[4 * (g) + 3], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); row_pass1<4 * (g) + 2, CIRC>(S[4 * (g) + 2], D[4 * (g) + 2], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); \
             row_pass1<4 * (g) + 1, CIRC>(S[4 * (g) + 1], D[4 * (g) + 1], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); row_pass1<4 * (g), CIRC>(S[4 * (g)], D[4 * (g)], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); \
             if (__builtin_expect(may_clip, 0)) { clip_row<4 * (g) + 3>(S[4 * (g) + 3], tbw); clip_row<4 * (g) + 2>(S[4 * (g) + 2], tbw); clip_row<4 * (g) + 1>(S[4 * (g) + 1], tbw); clip_row<4 * (g)>(S[4 * (g)], tbw); } \
@@ -499,7 +511,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         Col2 cl;
         cl.GE1 = GE1; cl.GO1 = GO1;
         cl.Iw = CHAIN_NONE; cl.extn = 0u;                                 // nothing arrives at the lane's first row from the lane itself
-#define P1B(g) if ((uint32_t)(g) < gl_x) { \
+#define P1B(g) if (GUARD(g)) { \
             const uint32_t tbl = tb_lane[(g) * 64];             /* (read here, used behind the four rows: no copy from group to group) */ \
             uint32_t eb = 0u; \
             const int32_t i3 = chain_row<4 * (g) + 3>(S[4 * (g) + 3], eb, cl), i2 = chain_row<4 * (g) + 2>(S[4 * (g) + 2], eb, cl); \
@@ -515,6 +527,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             tb_lane[(g) * 64] = tbw; }
         REP20(P1B)
 #undef P1B
+#undef GUARD
         RPROF(3)
         // ---- the insertion chain across the lanes ------------------------------------------------------------------------------------
         // E = the chain of the lane's own openers as it arrives BEHIND the lane's last row (pass 1b's last step ended there).
@@ -531,13 +544,14 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         const __amdgpu_buffer_rsrc_t rtb = __builtin_amdgcn_make_buffer_rsrc(tb0 + (size_t)(j - 1) * Rtot, 0, 0x7FFFFFFF, RSRC_WORD3);
         Recs R; R.bw = 0; R.gw = 0; R.g1 = 0;
         const uint32_t ycol = n - j;
-        uint32_t tbw0 = 0;                                               // group 0's traceback dword (row m's byte is in it)
+        uint32_t tbw0 = 0;                                               // the traceback dword of row m's group (gm: 0 or 1)
         const bool mine = lane == mlane;
-        // register k of group 0 holds a row below m (a row that takes part in the records) unless this is the lane of row m and
+        // register k of group gm holds a row below m (a row that takes part in the records) unless this is the lane of row m and
         // k <= pad (k < pad: no row at all; k == pad: row m itself)
+#define ROWM_GROUP(g) ((g) < 2 && (uint32_t)(g) == gm && mine)
 #define P2TAIL(g) \
-            const uint32_t t3 = ((g) == 0 && mine && 3u <= pad) ? 0u : S[4 * (g) + 3], t2 = ((g) == 0 && mine && 2u <= pad) ? 0u : S[4 * (g) + 2]; \
-            const uint32_t t1 = ((g) == 0 && mine && 1u <= pad) ? 0u : S[4 * (g) + 1], t0 = ((g) == 0 && mine) ? 0u : S[4 * (g)]; \
+            const uint32_t t3 = (ROWM_GROUP(g) && 3u <= pad) ? 0u : S[4 * (g) + 3], t2 = (ROWM_GROUP(g) && 2u <= pad) ? 0u : S[4 * (g) + 2]; \
+            const uint32_t t1 = (ROWM_GROUP(g) && 1u <= pad) ? 0u : S[4 * (g) + 1], t0 = ROWM_GROUP(g) ? 0u : S[4 * (g)]; \
             const uint32_t g4 = (t3 > t2 ? t3 : t2) > (t1 > t0 ? t1 : t0) ? (t3 > t2 ? t3 : t2) : (t1 > t0 ? t1 : t0); \
             group_records(R, g4, (uint32_t)(g)); \
             if ((int32_t)g4 >= ythr) {                       /* (two dword stores: a 64-bit one wants a register PAIR, i.e. a neighbour of the row's register saved and restored) */ \
@@ -548,23 +562,28 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                 if ((int32_t)t0 >= ythr) { __builtin_amdgcn_raw_buffer_store_b32(t0, ryr, vo, (4 * (g)) * 512, 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (4 * (g)) * 512 + 4, 0); } \
             } \
             __builtin_amdgcn_raw_buffer_store_b32(tbw, rtb, 4u * (uint32_t)lane_x, (g) * 256, AUX_NT); \
-            if ((g) == 0) tbw0 = tbw;
+            if ((g) < 2 && (uint32_t)(g) == gm) tbw0 = tbw;
         {
             ColA ca;
             ca.GE1 = GE1; ca.GO1 = GO1;
-            ca.X = Iin; ca.Sup = SUP_NONE; ca.xext = extin; ca.alive = ~0ull;
-#define P2(g) if ((uint32_t)(g) < gl_x) { \
+            ca.X = Iin; ca.Sup = SUP_NONE; ca.xext = extin;
+            // every lane starts in group gtop - 1: the lanes' alive state is scalar from the start, and group_alive runs under scalar
+            // conditions with every lane enabled (what it does to a lane that is not alive, or has no group 0, nobody looks at)
+            ca.alive = __ballot(gl > 0);
+            const unsigned long long have0 = __ballot(has0);
+#define P2(g) if ((uint32_t)(g) < gtop_x) { \
+            if ((g) == 0) ca.alive &= have0; \
             uint32_t tbw = tb_lane[(g) * 64]; \
-            if ((ca.alive & __ballot(true)) != 0ull) { RCOUNT(1) } \
-            if ((ca.alive & __ballot(true)) != 0ull) group_alive<(g)>(S[4 * (g) + 3], S[4 * (g) + 2], S[4 * (g) + 1], S[4 * (g)], tbw, ca, bs_lane); \
-            P2TAIL(g) \
-        } \
-        /* (assigned under a per-lane condition, the mask is a per-lane variable to the compiler: lane 0 is in every group) */ \
-        ca.alive = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ca.alive >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ca.alive);
+            if (ca.alive != 0ull) { RCOUNT(1) group_alive<(g)>(S[4 * (g) + 3], S[4 * (g) + 2], S[4 * (g) + 1], S[4 * (g)], tbw, ca, bs_lane); } \
+            if ((g) == 0 ? has0_x : true) { \
+                P2TAIL(g) \
+            } \
+        }
             REP20(P2)
 #undef P2
         }
 #undef P2TAIL
+#undef ROWM_GROUP
 
         RPROF(5)
         // ---- the contig's epilogue: wave reductions over rows < m, row m, the column arg-max granule --------------------------------
@@ -577,12 +596,12 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                                              w[1] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g) + 1], L); w[0] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g)], L); }
                 REP20(FETCH)
 #undef FETCH
-                if (G == 0u && L == mlane) { w[0] = 0u; if (pad >= 1u) w[1] = 0u; if (pad >= 2u) w[2] = 0u; if (pad >= 3u) w[3] = 0u; }
+                if (G == gm && L == mlane) { w[0] = 0u; if (pad >= 1u) w[1] = 0u; if (pad >= 2u) w[2] = 0u; if (pad >= 3u) w[3] = 0u; }
             };
             // 0-based row of register 4 G + k of lane L
             auto row_of = [&](const uint32_t G, const uint32_t k, const uint32_t L) -> uint32_t {
-                const uint32_t glL = gq + (L < grem ? 1u : 0u), rbL = 4u * (L * gq + (L < grem ? L : grem));
-                return rbL + 4u * glL - 1u - (4u * G + k);
+                const uint32_t glL = gq + (L < grem ? 1u : 0u), rbL = 4u * (L * gq + (L < grem ? L : grem)), rshL = (grem > 0 && L >= grem) ? 4u : 0u;
+                return rbL + 4u * glL - 1u - (4u * G + k - rshL);
             };
             // The granule the other waves wait for needs the column arg-max (largest score, topmost row, its length) and row m; the
             // x-suffix running maximum's ROW is only stored (Lx): it is looked up after the granule has gone out.
@@ -606,8 +625,8 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                 const uint32_t k1 = (w[3] >> 16) == smax ? 3u : (w[2] >> 16) == smax ? 2u : (w[1] >> 16) == smax ? 1u : 0u;
                 cb_.v = (int32_t)smax; cb_.row = row_of(G1, k1, (uint32_t)L1) + 1u; cb_.len = w[k1] & 0xFFFFu;
             }
-            // ---- row m (:350-351 seeded selection, :406-447 for i == m): register `pad` of lane mlane --------------------------------
-            const uint32_t wm = pad == 0 ? S[0] : pad == 1 ? S[1] : pad == 2 ? S[2] : S[3];
+            // ---- row m (:350-351 seeded selection, :406-447 for i == m): register 4 gm + pad of lane mlane ---------------------------
+            const uint32_t wm = gm == 0 ? (pad == 0 ? S[0] : pad == 1 ? S[1] : pad == 2 ? S[2] : S[3]) : (pad == 0 ? S[4] : pad == 1 ? S[5] : pad == 2 ? S[6] : S[7]);
             const int32_t dgm = cx.dgm;
             const uint32_t bytem = (tbw0 >> (8u * pad)) & 0xFFu;
             const int32_t ownW = (int32_t)__builtin_amdgcn_readlane((int)wm, mlane);
@@ -638,12 +657,15 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             const uint32_t lx = (do_x_m || xb_.row == 0u) ? 0u : m - xb_.row;
             if (cb_.v > vrun) vrun = cb_.v;
             rowm_xsuf = mvm == MK_XSUF; rowm_S = Sm; rowm_len = Slm;
-            if (mine) { if (pad == 0) S[0] = smw; else if (pad == 1) S[1] = smw; else if (pad == 2) S[2] = smw; else S[3] = smw; }   // the register of row m takes the seeded result
+            if (mine) {                                     // the register of row m takes the seeded result
+                if (gm == 0) { if (pad == 0) S[0] = smw; else if (pad == 1) S[1] = smw; else if (pad == 2) S[2] = smw; else S[3] = smw; }
+                else { if (pad == 0) S[4] = smw; else if (pad == 1) S[5] = smw; else if (pad == 2) S[6] = smw; else S[7] = smw; }
+            }
             if (mine) {
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(mvm | (ownByte & (TBB_IEXT | TBB_DEXT))), rtb, 4u * (uint32_t)lane + pad, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(mvm | (ownByte & (TBB_IEXT | TBB_DEXT))), rtb, 4u * (uint32_t)lane + pad, gm * 256u, 0);
                 const uint32_t rl = lastcol ? (do_x_m ? ownSl : xb_.len) : 0u;
                 if (Sm >= ybase) {
-                    const uint32_t yi = pad * 64u + (uint32_t)lane;
+                    const uint32_t yi = padreg * 64u + (uint32_t)lane;
                     bool upd = Slm > 0u;
                     if (lastcol) { const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(ryr, 8u * yi, 0, 0); const int32_t sn_ = word_score((int32_t)old.x); upd = Sm > sn_ || (Sm == sn_ && Slm > rl); }
                     if (upd) { u32x2 rec; rec.x = smw; rec.y = n - j; __builtin_amdgcn_raw_buffer_store_b64(rec, ryr, 8u * yi, 0, 0); }
@@ -655,18 +677,19 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     // ---- column n's arrays for the fix-up kernel (single_contig_aligner.rs:453-555): the final words, and the insertion chain at
     // every row — recomputed here from the final words (an opener taken from a merged cell gives the same chain, see above)
     {
-        int lane_x = lane; uint32_t gl_x = gl; int32_t pos_x = pos1_0; asm volatile("" : "+v"(lane_x), "+v"(gl_x), "+v"(pos_x));
-        const uint32_t rg4_x = 4u * (roff + (uint32_t)pos_x - 1u);       // 4 x (linear row index of register 0's row)
+        uint32_t gl_x = gl; int32_t pos_x = pos1_0; asm volatile("" : "+v"(gl_x), "+v"(pos_x));
+        const uint32_t rg4_x = 4u * (roff + (uint32_t)pos_x - 1u + rsh);       // 4 x (linear row index of the row register 0 holds, or would hold)
         const bool mine = lane == mlane;
         int32_t L = CHAIN_NONE; bool lext = false;
-#define LASTA(g) if ((uint32_t)(g) < gl_x) { _Pragma("unroll") for (int k = 3; k >= 0; --k) { \
+#define GUARD(g) ((g) == 0 ? has0 : (uint32_t)(g) < gtop)
+#define LASTA(g) if (GUARD(g)) { _Pragma("unroll") for (int k = 3; k >= 0; --k) { \
             const int32_t ext = L + GE1, open = (int32_t)S[4 * (g) + k] + GO1; lext = word_score(ext) >= word_score(open); L = lext ? ext : open; } }
         REP20(LASTA)
 #undef LASTA
         int32_t I; uint32_t extin;
         chain_across_lanes(L, lext, pos_x, gl_x, I, extin);
-#define LASTB(g) if ((uint32_t)(g) < gl_x) { _Pragma("unroll") for (int k = 3; k >= 0; --k) { \
-            if (!((g) == 0 && mine && (uint32_t)k < pad)) { \
+#define LASTB(g) if (GUARD(g)) { _Pragma("unroll") for (int k = 3; k >= 0; --k) { \
+            if (!((g) < 2 && (uint32_t)(g) == gm && mine && (uint32_t)k < pad)) { \
                 const uint32_t vo = rg4_x - 4u * (4 * (g) + k); \
                 __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score((int32_t)S[4 * (g) + k]), rS, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len((int32_t)S[4 * (g) + k]), rS, vo, oSlen, 0); \
                 __builtin_amdgcn_raw_buffer_store_b32((uint32_t)word_score(I), rS, vo, oIval, 0); __builtin_amdgcn_raw_buffer_store_b32(word_len(I), rS, vo, oIlen, 0); \
@@ -674,6 +697,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             const int32_t ext = I + GE1, open = (int32_t)S[4 * (g) + k] + GO1; I = word_score(ext) >= word_score(open) ? ext : open; } }
         REP20(LASTB)
 #undef LASTB
+#undef GUARD
     }
 #ifdef STITCH_PROFILE
     RPROF(6)
@@ -684,7 +708,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     for (uint32_t i = 0; i < nrows; ++i) {
         const uint32_t row = rowbase + (nrows - 1 - i);
         if (row < m) {
-            const u32x2 rec = yrec[roff + i * 64u + (uint32_t)lane];
+            const u32x2 rec = yrec[roff + (i + rsh) * 64u + (uint32_t)lane];
             V.Sn[roff + row] = word_score((int32_t)rec.x); V.SnLen[roff + row] = word_len((int32_t)rec.x); V.Ly[roff + row] = rec.y;
         }
     }

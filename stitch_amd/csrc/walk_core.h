@@ -84,8 +84,8 @@ STITCH_HD void decode_src(const JobView& V, uint32_t c, uint32_t i, uint32_t j, 
 // Where the traceback byte of row i (1-based) of a contig of m rows sits within a column's bytes of that contig.  The tiled
 // kernels store rows linearly.  fill_regs.hip stores them lane-interleaved: the contig's ceil(m / 4) groups of four rows are
 // dealt to the 64 lanes of its wave in order (the first `grem` lanes hold one group more), a lane's rows fill its registers
-// nrows-1 .. 0 top to bottom, and register idx of lane l goes to byte ((idx >> 2) * 64 + l) * 4 + (idx & 3), so that one store
-// instruction writes whole lines.
+// from the fullest lane's top register downwards (the lanes with a group less end in register 4, not 0), and register idx of lane l
+// goes to byte ((idx >> 2) * 64 + l) * 4 + (idx & 3), so that one store instruction writes whole lines.
 STITCH_HD uint32_t tb_row_offset(uint32_t keyfmt, uint32_t m, uint32_t i) {
     if (keyfmt != 2) return i - 1;
     const uint32_t ngr = (m + 3) / 4, gq = ngr / 64, grem = ngr % 64, row = i - 1;
@@ -93,7 +93,7 @@ STITCH_HD uint32_t tb_row_offset(uint32_t keyfmt, uint32_t m, uint32_t i) {
     uint32_t lane, uu, nrows;
     if (row < grem * big) { lane = row / big; uu = row - lane * big; nrows = big; }
     else { const uint32_t rr = row - grem * big; lane = grem + rr / small; uu = rr - (lane - grem) * small; nrows = small; }
-    const uint32_t idx = nrows - 1 - uu;
+    const uint32_t idx = nrows - 1 - uu + ((grem > 0 && lane >= grem) ? 4u : 0u);     // (the lanes that hold a group less have it at the bottom: group 0 is not theirs)
     return ((idx >> 2) * 64 + lane) * 4 + (idx & 3);
 }
 

@@ -21,7 +21,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 def compile_asm(src, tmp_path, *defs):
     out = os.path.join(str(tmp_path), os.path.basename(src) + ".s")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, src), "-o", out] + list(defs)
+    from stitch_amd import build as sbuild
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, src), "-o", out] + \
+          sbuild.FILE_FLAGS.get(src, []) + list(defs)          # (the flags the product build gives this file)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     # (-S does not run the assembler: an operand an inline asm statement cannot take only shows when the listing is assembled)

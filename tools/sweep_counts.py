@@ -7,11 +7,11 @@ def rep(a, b):
     global s
     assert a in s, a
     s = s.replace(a, b, 1)
-rep('#define P1(g) if ((uint32_t)(g) < gl_x) { uint32_t tbw; \\', '#define P1(g) if ((uint32_t)(g) < gl_x) { uint32_t tbw; asm volatile("; P1G_BEGIN"); \\')
+rep('#define P1(g) if (GUARD(g)) { uint32_t tbw; \\', '#define P1(g) if (GUARD(g)) { uint32_t tbw; asm volatile("; P1G_BEGIN"); \\')
 rep('            tb_lane[(g) * 64] = tbw; }\n        REP20(P1)', '            tb_lane[(g) * 64] = tbw; asm volatile("; P1G_END"); }\n        REP20(P1)')
-rep('#define P1B(g) if ((uint32_t)(g) < gl_x) { \\', '#define P1B(g) if ((uint32_t)(g) < gl_x) { asm volatile("; P1BG_BEGIN"); \\')
+rep('#define P1B(g) if (GUARD(g)) { \\', '#define P1B(g) if (GUARD(g)) { asm volatile("; P1BG_BEGIN"); \\')
 rep('            tb_lane[(g) * 64] = tbw; }\n        REP20(P1B)', '            tb_lane[(g) * 64] = tbw; asm volatile("; P1BG_END"); }\n        REP20(P1B)')
-rep('            P2TAIL(g) \\\n        } \\', '            asm volatile("; TAIL_BEGIN"); P2TAIL(g) asm volatile("; TAIL_END"); \\\n        } \\')
+rep('                P2TAIL(g) \\', '                asm volatile("; TAIL_BEGIN"); P2TAIL(g) asm volatile("; TAIL_END"); \\')
 tmp = os.path.join(root, 'stitch_amd/csrc/_m.hip')
 open(tmp, 'w').write(s)
 try:
