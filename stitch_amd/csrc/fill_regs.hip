@@ -542,6 +542,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         // ---- pass 2: where the arriving chain is alive, its extended bits and its merge (row_alive); per group the lane's running
         // records, y-suffix records and the traceback dword; in the last column also the int32 arrays the fix-up kernel reads -----------
         const __amdgpu_buffer_rsrc_t rtb = __builtin_amdgcn_make_buffer_rsrc(tb0 + (size_t)(j - 1) * Rtot, 0, 0x7FFFFFFF, RSRC_WORD3);
+        const gptr<uint32_t> tbcol = (gptr<uint32_t>)as_global(tb0 + (size_t)(j - 1) * Rtot), tbcol_hi = tbcol + 12 * 64;
         Recs R; R.bw = 0; R.gw = 0; R.g1 = 0;
         const uint32_t ycol = n - j;
         uint32_t tbw0 = 0;                                               // the traceback dword of row m's group (gm: 0 or 1)
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                 if ((int32_t)t1 >= ythr) { __builtin_amdgcn_raw_buffer_store_b32(t1, ryr, vo, (4 * (g) + 1) * 512, 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (4 * (g) + 1) * 512 + 4, 0); } \
                 if ((int32_t)t0 >= ythr) { __builtin_amdgcn_raw_buffer_store_b32(t0, ryr, vo, (4 * (g)) * 512, 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (4 * (g)) * 512 + 4, 0); } \
             } \
-            __builtin_amdgcn_raw_buffer_store_b32(tbw, rtb, 4u * (uint32_t)lane_x, (g) * 256, AUX_NT); \
+            __builtin_nontemporal_store(tbw, ((g) < 12 ? tbcol : tbcol_hi) + (((g) < 12 ? (g) : (g) - 12) * 64 + lane_x));      /* scalar base + lane offset + immediate (< 4 KB) */ \
             if ((g) < 2 && (uint32_t)(g) == gm) tbw0 = tbw;
         {
             ColA ca;

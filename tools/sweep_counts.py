@@ -15,7 +15,7 @@ rep('                P2TAIL(g) \\', '                asm volatile("; TAIL_BEGIN"
 tmp = os.path.join(root, 'stitch_amd/csrc/_m.hip')
 open(tmp, 'w').write(s)
 try:
-    subprocess.run(['/opt/rocm/bin/hipcc', '-w', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', tmp, '-o', '/tmp/m.s'], check=True)
+    subprocess.run(['/opt/rocm/bin/hipcc', '-w', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-mllvm', '-amdgpu-sched-strategy=iterative-ilp', tmp, '-o', '/tmp/m.s'], check=True)
 finally:
     os.remove(tmp)
 L = open('/tmp/m.s').read().split('\n')
@@ -26,6 +26,6 @@ for tag in ['P1G', 'P1BG', 'TAIL']:
         if '; %s_BEGIN' % tag in L[i]:
             j = i
             while '; %s_END' % tag not in L[j] and j < end: j += 1
-            res.append((sum(1 for l in L[i:j] if re.match(r'\s+v_', l)), sum(1 for l in L[i:j] if re.match(r'\s+s_', l)), sum(1 for l in L[i:j] if 's_cbranch' in l), sum(1 for l in L[i:j] if 'v_mov_b32' in l))); i = j
+            res.append((sum(1 for l in L[i:j] if re.match(r'\s+v_', l)), sum(1 for l in L[i:j] if re.match(r'\s+s_', l)), sum(1 for l in L[i:j] if 's_cbranch' in l), sum(1 for l in L[i:j] if 'v_mov_b32' in l), sum(1 for l in L[i:j] if 'v_readlane' in l), sum(1 for l in L[i:j] if 's_nop' in l), sum(1 for l in L[i:j] if 's_waitcnt' in l))); i = j
         i += 1
-    print(tag, len(res), '(valu, salu, branches, v_mov) per group:', res[:10])
+    print(tag, len(res), '(valu, salu, branches, v_mov, v_readlane, s_nop, s_waitcnt) per group:', res[:10])
