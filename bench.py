@@ -208,7 +208,15 @@ def main():
                 out["roofline"]["valu"] = {"wave_insts_per_64_cells": vpc, "achieved_wave_insts_per_s": vpc * (cells / 64.0) / fill_s,
                                            "peak_wave_insts_per_s": peak, "frac": vpc * (cells / 64.0) / fill_s / peak,
                                            "peak_source": "CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 integer instruction (measured: profiles/ubench/valu_issue_mi355x.txt)"}
-                out["roofline"]["binding"] = "valu_issue"
+                # ... and every other instruction takes an issue turn of its SIMD as well (two waves per SIMD rarely issue side by side:
+                # both mostly want the vector pipe): all instructions of the kernel against the same one-per-four-cycles peak
+                names = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")
+                if all(n_ in k for n_ in names):
+                    ipc = sum(k[n_]["avg_per_launch_raw"] for n_ in names) * 64.0 / cpl
+                    out["roofline"]["issue"] = {"wave_insts_per_64_cells": ipc, "achieved_wave_insts_per_s": ipc * (cells / 64.0) / fill_s,
+                                                "peak_wave_insts_per_s": peak, "frac": ipc * (cells / 64.0) / fill_s / peak,
+                                                "what": "vector + scalar + LDS + memory instructions (PMC) against one issue turn per SIMD and four cycles at 2.4 GHz"}
+                out["roofline"]["binding"] = "simd_issue"
                 if "SQ_WAVE_CYCLES" in k and "SQ_WAIT_ANY" in k:
                     wc = k["SQ_WAVE_CYCLES"]["avg_per_launch_raw"]
                     out["roofline"]["wave_time_split"] = {n_: k[c_]["avg_per_launch_raw"] / wc for n_, c_ in
