@@ -496,7 +496,9 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         // (the smaller of the column's jump words, plus the worse of match and mismatch: a lower bound of every cell's jump candidate)
         const int32_t jw_floor = (word_score(JSW1) < word_score(JSW) ? word_score(JSW1) : word_score(JSW)) + (P.mismatch < P.match ? P.mismatch : P.match);
         const bool may_clip = __builtin_amdgcn_readfirstlane(jw_floor) < 0;
-#define GUARD(g) ((g) == 0 ? has0_x : (uint32_t)(g) < gtop_x)    /* per lane for group 0 only; the other groups under a scalar condition */
+/* per lane for group 0 only; the other groups under a scalar condition, compared where it is used (kept as twenty boolean masks the
+   conditions of a sweep take forty scalar registers) */
+#define GUARD(g) ((g) == 0 ? has0_x : ({ asm volatile("" : "+s"(gtop_x)); (uint32_t)(g) < gtop_x; }))
 #define P1(g) if (GUARD(g)) { uint32_t tbw; \
             row_pass1<4 * (g) + 3, CIRC>(S[4 * (g) + 3], D[4 * (g) + 3], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); row_pass1<4 * (g) + 2, CIRC>(S[4 * (g) + 2], D[4 * (g) + 2], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); \
             row_pass1<4 * (g) + 1, CIRC>(S[4 * (g) + 1], D[4 * (g) + 1], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); row_pass1<4 * (g), CIRC>(S[4 * (g)], D[4 * (g)], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); \
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             // conditions with every lane enabled (what it does to a lane that is not alive, or has no group 0, nobody looks at)
             ca.alive = __ballot(gl > 0);
             const unsigned long long have0 = __ballot(has0);
-#define P2(g) if ((uint32_t)(g) < gtop_x) { \
+#define P2(g) if (({ asm volatile("" : "+s"(gtop_x)); (uint32_t)(g) < gtop_x; })) { \
             if ((g) == 0) ca.alive &= have0; \
             uint32_t tbw = tb_lane[(g) * 64]; \
             if (ca.alive != 0ull) { RCOUNT(1) group_alive<(g)>(S[4 * (g) + 3], S[4 * (g) + 2], S[4 * (g) + 1], S[4 * (g)], tbw, ca, bs_lane); } \
@@ -593,9 +595,9 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             // the four words of group G of lane L as the records saw them (the registers of row m and of no row count as 0)
             auto fetch4 = [&](const uint32_t G, const int L, uint32_t (&w)[4]) {
                 w[0] = w[1] = w[2] = w[3] = 0u;
-#define FETCH(g) if (G == (uint32_t)(g)) { w[3] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g) + 3], L); w[2] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g) + 2], L); \
-                                             w[1] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g) + 1], L); w[0] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g)], L); }
-                REP20(FETCH)
+#define FETCH(g) case (g): w[3] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g) + 3], L); w[2] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g) + 2], L); \
+                           w[1] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g) + 1], L); w[0] = (uint32_t)__builtin_amdgcn_readlane((int)S[4 * (g)], L); break;
+                switch (G) { REP20(FETCH) default: break; }      // (a search tree of scalar compares, not twenty in a row)
 #undef FETCH
                 if (G == gm && L == mlane) { w[0] = 0u; if (pad >= 1u) w[1] = 0u; if (pad >= 2u) w[2] = 0u; if (pad >= 3u) w[3] = 0u; }
             };
