@@ -588,6 +588,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             for (uint32_t a = 0; a < c.C; ++a) {
                 ContigDesc d{}; d.m = c.al[a].m; d.troff = c.al[a].troff; d.seqoff = c.al[a].seqoff; d.target = c.al[a].target; d.opp = c.al[a].opp;
                 d.roff = 0;
+                { const uint32_t ngr = (d.m + 3) / 4, gq = ngr / 64; d.inv_big = tb_div_magic(4 * (gq + 1)); d.inv_small = tb_div_magic(4 * gq); }
                 if (isact[a]) { d.roff = roff; roff += (d.m + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS; }
                 cd[a] = d;
                 // the opposite strand only counts when it is part of the current subset (multi_contig_aligner.rs:241-262)

@@ -16,7 +16,7 @@ struct ContigDesc {            // one per (contig, strand) aligner
     uint32_t seqoff;           // offset of base 0 in the packed sequence array
     uint32_t target;           // index of the FASTA record (contig_idx % T)
     int32_t opp;               // aligner index of the same-name opposite strand, -1 if none (double_strand only)
-    uint32_t pad[2];
+    uint32_t inv_big, inv_small;   // fill_regs.hip's row -> lane mapping without a division: floor(2^32 / d) + 1 for d = rows of a full / a short lane (tb_row_offset)
 };
 
 struct ChainHdr {              // == Alignment (align/alignment.rs:16-51)
@@ -86,13 +86,15 @@ STITCH_HD void decode_src(const JobView& V, uint32_t c, uint32_t i, uint32_t j, 
 // dealt to the 64 lanes of its wave in order (the first `grem` lanes hold one group more), a lane's rows fill its registers
 // from the fullest lane's top register downwards (the lanes with a group less end in register 4, not 0), and register idx of lane l
 // goes to byte ((idx >> 2) * 64 + l) * 4 + (idx & 3), so that one store instruction writes whole lines.
-STITCH_HD uint32_t tb_row_offset(uint32_t keyfmt, uint32_t m, uint32_t i) {
+STITCH_HD uint32_t tb_div_magic(uint32_t d) { return d ? (uint32_t)(0x100000000ull / d) + 1u : 0u; }      // exact quotients for n * d < 2^32
+STITCH_HD uint32_t tb_row_offset(uint32_t keyfmt, const ContigDesc& d, uint32_t i) {
     if (keyfmt != 2) return i - 1;
-    const uint32_t ngr = (m + 3) / 4, gq = ngr / 64, grem = ngr % 64, row = i - 1;
+    const uint32_t ngr = (d.m + 3) / 4, gq = ngr / 64, grem = ngr % 64, row = i - 1;
     const uint32_t big = 4 * (gq + 1), small = 4 * gq;
     uint32_t lane, uu, nrows;
-    if (row < grem * big) { lane = row / big; uu = row - lane * big; nrows = big; }
-    else { const uint32_t rr = row - grem * big; lane = grem + rr / small; uu = rr - (lane - grem) * small; nrows = small; }
+    // (the walk asks for a cell's byte several times per step: a multiplication by the contig's precomputed reciprocal, not a division)
+    if (row < grem * big) { lane = (uint32_t)(((unsigned long long)row * d.inv_big) >> 32); uu = row - lane * big; nrows = big; }
+    else { const uint32_t rr = row - grem * big; const uint32_t q = (uint32_t)(((unsigned long long)rr * d.inv_small) >> 32); lane = grem + q; uu = rr - q * small; nrows = small; }
     const uint32_t idx = nrows - 1 - uu + ((grem > 0 && lane >= grem) ? 4u : 0u);     // (the lanes that hold a group less have it at the bottom: group 0 is not theirs)
     return ((idx >> 2) * 64 + lane) * 4 + (idx & 3);
 }
@@ -100,7 +102,7 @@ STITCH_HD uint32_t tb_row_offset(uint32_t keyfmt, uint32_t m, uint32_t i) {
 // Traceback byte of cell (i,j) in the generic move codes.  The Local-mode kernel writes key-format bytes (dp_core.h)
 // and flags "row 1 took the circular jump" in bit 31 of the column's jump-table entry.
 STITCH_HD uint32_t tb_byte(const JobView& V, uint32_t c, uint32_t i, uint32_t j) {
-    const uint32_t raw = V.tb[(size_t)(j - 1) * V.Rtot + V.cd[c].roff + tb_row_offset(V.tb_keyfmt, V.cd[c].m, i)];
+    const uint32_t raw = V.tb[(size_t)(j - 1) * V.Rtot + V.cd[c].roff + tb_row_offset(V.tb_keyfmt, V.cd[c], i)];
     if (!V.tb_keyfmt) return raw;
     return key_code_to_generic(raw, i == 1 && (V.jt_idx[(size_t)c * (V.n + 1) + j] & JT_CIRC_BIT) != 0);
 }
