@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         const int lane_x = lane; uint32_t gl_x = gl; int32_t pos_x = pos1_0; bool has0_x = has0; asm volatile("" : "+v"(gl_x), "+v"(pos_x)); { uint32_t h = has0 ? 1u : 0u; asm volatile("" : "+v"(h)); has0_x = h != 0u; }
         uint32_t gtop_x = gtop; asm volatile("" : "+s"(gtop_x));        // (opaque: the compiler would keep twenty compare results per sweep in scalar registers)
         const uint32_t* const xw_lane = (const uint32_t*)(s_wave + LDS_XW) + lane_x;
-        uint32_t* const tb_lane = (uint32_t*)(s_wave + LDS_TB) + lane_x;
+        uint32_t tbv[NG];                              // the groups' traceback dwords, from sweep to sweep in registers (the kernel has them to spare)
         uint16_t* const bs_lane = (uint16_t*)(s_wave + LDS_BS) + lane_x;
 
         RPROF(1)
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             row_pass1<4 * (g) + 3, CIRC>(S[4 * (g) + 3], D[4 * (g) + 3], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); row_pass1<4 * (g) + 2, CIRC>(S[4 * (g) + 2], D[4 * (g) + 2], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); \
             row_pass1<4 * (g) + 1, CIRC>(S[4 * (g) + 1], D[4 * (g) + 1], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); row_pass1<4 * (g), CIRC>(S[4 * (g)], D[4 * (g)], tbw, cx, XC(g), XN(g), xw_lane, bs_lane); \
             if (__builtin_expect(may_clip, 0)) { clip_row<4 * (g) + 3>(S[4 * (g) + 3], tbw); clip_row<4 * (g) + 2>(S[4 * (g) + 2], tbw); clip_row<4 * (g) + 1>(S[4 * (g) + 1], tbw); clip_row<4 * (g)>(S[4 * (g)], tbw); } \
-            tb_lane[(g) * 64] = tbw; }
+            tbv[g] = tbw; }
         REP20(P1)
 #undef P1
 #undef XC
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
         cl.GE1 = GE1; cl.GO1 = GO1;
         cl.Iw = CHAIN_NONE; cl.extn = 0u;                                 // nothing arrives at the lane's first row from the lane itself
 #define P1B(g) if (GUARD(g)) { \
-            const uint32_t tbl = tb_lane[(g) * 64];             /* (read here, used behind the four rows: no copy from group to group) */ \
+            const uint32_t tbl = tbv[g]; \
             uint32_t eb = 0u; \
             const int32_t i3 = chain_row<4 * (g) + 3>(S[4 * (g) + 3], eb, cl), i2 = chain_row<4 * (g) + 2>(S[4 * (g) + 2], eb, cl); \
             const int32_t i1 = chain_row<4 * (g) + 1>(S[4 * (g) + 1], eb, cl), i0 = chain_row<4 * (g)>(S[4 * (g)], eb, cl); \
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                 merge_row<4 * (g) + 3>(S[4 * (g) + 3], tbw, __ballot(m3), i3, bs_lane); merge_row<4 * (g) + 2>(S[4 * (g) + 2], tbw, __ballot(m2), i2, bs_lane); \
                 merge_row<4 * (g) + 1>(S[4 * (g) + 1], tbw, __ballot(m1), i1, bs_lane); merge_row<4 * (g)>(S[4 * (g)], tbw, __ballot(m0), i0, bs_lane); \
             } \
-            tb_lane[(g) * 64] = tbw; }
+            tbv[g] = tbw; }
         REP20(P1B)
 #undef P1B
 #undef GUARD
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
             const unsigned long long have0 = __ballot(has0);
 #define P2(g) if (({ asm volatile("" : "+s"(gtop_x)); (uint32_t)(g) < gtop_x; })) { \
             if ((g) == 0) ca.alive &= have0; \
-            uint32_t tbw = tb_lane[(g) * 64]; \
+            uint32_t tbw = tbv[g]; \
             if (ca.alive != 0ull) { RCOUNT(1) group_alive<(g)>(S[4 * (g) + 3], S[4 * (g) + 2], S[4 * (g) + 1], S[4 * (g)], tbw, ca, bs_lane); } \
             if ((g) == 0 ? has0_x : true) { \
                 P2TAIL(g) \
