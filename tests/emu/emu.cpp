@@ -374,4 +374,12 @@ long emu_job(void* h, const uint8_t* y, uint32_t n, const uint32_t* act, uint32_
     return nch;
 }
 
+// fill_regs.hip's row -> byte mapping of the lane-interleaved traceback layout, as the walk computes it (walk_core.h)
+uint32_t emu_tb_row_offset(uint32_t m, uint32_t i) {
+    ContigDesc d{}; d.m = m;
+    const uint32_t ngr = (m + 3) / 4, gq = ngr / 64;
+    d.inv_big = tb_div_magic(4 * (gq + 1)); d.inv_small = tb_div_magic(4 * gq);
+    return tb_row_offset(2, d, i);
+}
+
 }  // extern "C"
