@@ -70,9 +70,10 @@ def main():
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--contigs", type=int, default=50)
     ap.add_argument("--contig-len", type=int, default=5000)
-    ap.add_argument("--cpu-reads", type=int, default=-1, help="reads in the cpu_baseline sample (-1 = one per worker thread, 0 = skip)")
-    ap.add_argument("--cpu-prefix", type=int, default=2500, help="bases of each sample read the CPU aligns (0 = whole read: 40 GB and minutes per read)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="worker threads of the CPU leg (0 = min(cores, free RAM / RAM per worker, 4))")
+    ap.add_argument("--cpu-reads", type=int, default=-1, help="0 = skip the cpu_baseline leg")
+    ap.add_argument("--cpu-reads-per-worker", type=int, default=2, help="timed reads per worker thread of the CPU leg (>= 2; one more is aligned as warm-up)")
+    ap.add_argument("--cpu-prefix", type=int, default=400, help="bases of each sample read the CPU aligns (0 = whole read: 40 GB and minutes per read)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="worker threads of the CPU leg (0 = min(cores, free RAM / RAM per worker, CPU share of the box))")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,6 +131,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     fill_ms = walk_ms = 0.0
+    clk_cycles = clk_ticks = 0
     cells = 0
     launches = 0
     mapped = 0
@@ -139,6 +141,7 @@ def main():
         rr, ch, _ops = aligners.align_packed_raw(*batches[s])       # result arena views: what a compiled front end would read
         tm = aligners.timing()
         fill_ms += tm["fill_ms"]; walk_ms += tm["walk_ms"]; cells += tm["cells"]; launches += tm["launches"]
+        clk_cycles += tm.get("clk_shader_cycles", 0); clk_ticks += tm.get("clk_ref_ticks", 0)
         kernel_name = FILL_KERNELS.get(tm.get("fill_kind", 1), kernel_name)
         n_mine += my_reads[s]
         if len(ch):
@@ -179,6 +182,12 @@ def main():
                          "avg_launch_ms": fill_ms / max(1, launches), "walk_kernel_ms_per_step": walk_ms / args.steps,
                          "fill_gcells_per_sec": cells / fill_s / 1e9 if fill_s > 0 else 0.0},
         }
+        # the shader clock the fill ran at, measured inside the kernel over the timed launches (s_memtime against the 100 MHz
+        # s_memrealtime; fill_regs.hip).  The issue roofline below is priced at the nominal 2.4 GHz AND at this clock.
+        clock_mhz = clk_cycles / clk_ticks * 100.0 if clk_ticks else None
+        if clock_mhz:
+            out["roofline"]["clock"] = {"in_kernel_mhz": clock_mhz, "nominal_mhz": SHADER_CLOCK_HZ / 1e6,
+                                        "how": "s_memtime / s_memrealtime over the column loop of every timed fill launch; profiles/*_clock.txt holds the smi and PMC views"}
         # HBM-side traffic and the wave-time split of the fill kernel: PMC counters cannot be read from inside this process, so
         # the figures are the committed rocprofv3 --pmc measurement (profiles/, separate FETCH_SIZE and WRITE_SIZE passes of this
         # same command, KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled per cell — and only
@@ -216,6 +225,10 @@ def main():
                     out["roofline"]["issue"] = {"wave_insts_per_64_cells": ipc, "achieved_wave_insts_per_s": ipc * (cells / 64.0) / fill_s,
                                                 "peak_wave_insts_per_s": peak, "frac": ipc * (cells / 64.0) / fill_s / peak,
                                                 "what": "vector + scalar + LDS + memory instructions (PMC) against one issue turn per SIMD and four cycles at 2.4 GHz"}
+                    if clock_mhz:
+                        peak_m = prop.multi_processor_count * 4 * clock_mhz * 1e6 / VALU_CYCLES_PER_WAVE_INST
+                        out["roofline"]["issue"]["frac_at_measured_clock"] = ipc * (cells / 64.0) / fill_s / peak_m
+                        out["roofline"]["valu"]["frac_at_measured_clock"] = vpc * (cells / 64.0) / fill_s / peak_m
                 out["roofline"]["binding"] = "simd_issue"
                 if "SQ_WAVE_CYCLES" in k and "SQ_WAIT_ANY" in k:
                     wc = k["SQ_WAVE_CYCLES"]["avg_per_launch_raw"]
@@ -234,38 +247,59 @@ def main():
 
 def cpu_leg(args, db, stream, aligners):
     """the C++ restatement of the reference with the reference's worker model — T threads, one aligner set
-    (16-byte row-major traceback matrices of every contig) per thread, chunks of 10 records — on a bounded sample of the
-    same read stream; SAM text from both sides diffed on that sample."""
+    (16-byte row-major traceback matrices of every contig) per thread — on a bounded sample of the same read stream, WARM: every
+    worker builds its aligner set and aligns one read before the clock starts (the reference allocates a thread's matrices once,
+    align/traceback/mod.rs:93-126; first-touch page faults are a property of a fresh process), the clock stops before anything is
+    freed, and each worker aligns >= 2 timed reads.  T = min(cores, free RAM / RAM per worker, the box's CPU share); the scaling
+    from one thread up to T is measured and printed.  SAM text from both sides is diffed on the sample."""
     from oracle import oracle as orc
     pre = args.cpu_prefix if 0 < args.cpu_prefix < args.read_len else args.read_len
     rows = args.contigs * (args.contig_len + 1)
     ram_per_worker = rows * (pre + 1) * 16                      # traceback/mod.rs:122-126
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     free = host_memory_available()
-    # (more workers do not help: the reference's 16-byte row-major cells make every cell a cache and TLB miss, and 16 workers
-    # aligned 38 Mcells/s together and 8 workers 26 where one aligns 25 on the same host — measured, DESIGN.md; four keep the leg
-    # under two minutes)
-    T = args.cpu_threads if args.cpu_threads > 0 else max(1, min(cores, int(free * 0.6 // max(1, ram_per_worker)), 4))
-    n_sample = args.cpu_reads if args.cpu_reads > 0 else T
+    # BASELINE.md 3: T = min(cores, free RAM / per-worker RAM); a one-GPU box lends this job a CPU share of 16 (gpurun)
+    share = int(os.environ.get("STITCH_CPU_SHARE", "16"))
+    T = args.cpu_threads if args.cpu_threads > 0 else max(1, min(cores, int(free * 0.6 // max(1, ram_per_worker)), share))
+    per_worker = max(2, args.cpu_reads_per_worker)
     # distinct reads (a duplicated neighbour is the same job for both sides), each cut to the stated prefix
-    sample = []
-    for r in stream:
-        if not sample or r != stream[len(sample) - 1]:
-            sample.append(r[:pre])
-        if len(sample) == n_sample:
+    cut = []
+    for i, r in enumerate(stream):
+        if i == 0 or r != stream[i - 1]:
+            cut.append(r[:pre])
+        if len(cut) == per_worker * T:
             break
-    secs, ccells, _scores, csam = orc.cpu_bench_sam([(n, s) for n, s in db], sample, threads=T, name_base=0)
+    targets = [(n, s) for n, s in db]
+    cells_per_read = args.read_len * args.contigs * args.contig_len
+    # scaling: one thread, a few, all — each level times `per_worker` reads per worker after one warm-up read per worker
+    levels = sorted({1, min(4, T), T})
+    scaling = []
+    secs = ccells = 0
+    csam = busy = None
+    for t in levels:
+        sample = cut[:per_worker * t]
+        secs, ccells, _scores, csam, busy = orc.cpu_bench_sam(targets, sample, threads=t, name_base=0, chunk=1, warm=1)
+        scaling.append({"threads": t, "reads": len(sample), "seconds": round(secs, 2), "mcells_per_sec": round(ccells / secs / 1e6, 1),
+                        "mcells_per_sec_per_thread": round(ccells / secs / 1e6 / t, 1)})
+    sample = cut[:per_worker * T]
     # the same sample through the HIP path: SAM text must be identical (parity proper is tests/, this is the run-time diff)
     aligners.align(sample)
     gsam = ["".join(l + "\n" for l in aligners.format_sam(k, f"read_{k:07d}", sample[k], b"I" * len(sample[k]))) for k in range(len(sample))]
     same = [g == c for g, c in zip(gsam, csam)]
-    cells_per_read = args.read_len * args.contigs * args.contig_len
-    return {"value": ccells / secs / cells_per_read, "unit": "reads/s", "cores": T, "kind": "port",
-            "gcells_per_sec": ccells / secs / 1e9, "sam_identical_on_sample": bool(all(same)), "sam_reads_compared": len(same),
-            "sample": f"first {pre} bp of the first {len(sample)} distinct read(s) vs the full DB: {ccells} cells in {secs:.1f} s on {T} worker "
-                      f"thread(s) (one aligner set per thread, chunks of 10 records; {cores} cores usable, {free / 2**30:.0f} GiB host RAM "
-                      f"available, {ram_per_worker / 2**30:.1f} GiB of 16-byte traceback cells per worker); reads/s = cells/s / {cells_per_read} "
-                      f"cells per {args.read_len} bp read; C++ restatement of fulcrumgenomics/stitch (g++ -O3, portable flags), not the Rust binary"}
+    per_thread = ccells / secs / 1e6 / T
+    eff = scaling[-1]["mcells_per_sec"] / max(1e-9, scaling[0]["mcells_per_sec"] * T)
+    why = "" if eff >= 0.7 else (f"; {T} threads reach {eff:.0%} of {T} x the one-thread rate: every cell is a 16-byte store into a row-major "
+                                 f"(m+1) x (n+1) matrix (a new cache line and page per row), so the workers contend for memory bandwidth and TLB reach, not for cores")
+    return {"value": ccells / secs / cells_per_read, "unit": "reads/s", "cores": T, "kind": "port", "warm": True,
+            "gcells_per_sec": ccells / secs / 1e9, "mcells_per_sec_per_thread": per_thread, "scaling": scaling,
+            "sam_identical_on_sample": bool(all(same)), "sam_reads_compared": len(same),
+            "sample": f"first {pre} bp of the first {len(sample)} distinct reads vs the full DB, {per_worker} timed reads per worker after one warm-up read per "
+                      f"worker (matrices allocated and touched before the clock; the clock stops before they are freed): {ccells} cells in {secs:.1f} s on {T} "
+                      f"worker threads = {per_thread:.1f} Mcells/s per thread (one aligner set per thread, one record per pull; {cores} cores visible, CPU share "
+                      f"of the box {share}, {free / 2**30:.0f} GiB host RAM available, {ram_per_worker / 2**30:.1f} GiB of 16-byte traceback cells per worker; "
+                      f"T = min(cores, RAM / per-worker RAM, share)); scaling {', '.join(str(x['threads']) + ' thr: ' + str(x['mcells_per_sec']) + ' Mcells/s' for x in scaling)}"
+                      f"{why}; reads/s = cells/s / {cells_per_read} cells per {args.read_len} bp read; C++ restatement of fulcrumgenomics/stitch "
+                      f"(g++ -O3, portable flags), not the Rust binary"}
 
 
 if __name__ == "__main__":

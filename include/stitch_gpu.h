@@ -101,7 +101,9 @@ typedef struct stitch_timing { double fill_ms, walk_ms, h2d_ms, d2h_ms, host_ms;
                                   threads concurrently with prealign_ms of the chunk before, so the two overlap */;
                                uint32_t fill_kind /* kernel of the last fill launch: 0 generic int32, 1 Local-mode streaming, 2 Local-mode register-resident */,
                                         wg_per_read /* workgroups that shared one read in that launch */,
-                                        fallbacks /* launches repeated with one workgroup per read after a partner timeout */, pad_; } stitch_timing;
+                                        fallbacks /* launches repeated with one workgroup per read after a partner timeout */, pad_;
+                               uint64_t clk_shader_cycles, clk_ref_ticks /* register-resident fill only: shader cycles (s_memtime) and 100 MHz ticks
+                                  (s_memrealtime) over the column loop of the first read of every launch, summed: cycles / ticks x 100 = MHz */; } stitch_timing;
 int stitch_last_timing(const stitch_ctx*, stitch_timing* out);
 
 /* Test hook (host only, no device needed): the band of the pre-alignment filter for one (read, target strand) pair as the

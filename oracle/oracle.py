@@ -43,7 +43,7 @@ def lib():
         _lib.orc_al_new.restype = C.c_void_p
         _lib.orc_al_cells.restype = C.c_uint64
         _lib.orc_bench.restype = C.c_double
-        _lib.orc_bench_sam.restype = C.c_double
+        _lib.orc_bench_warm.restype = C.c_double
     return _lib
 
 
@@ -277,9 +277,11 @@ def cpu_bench(targets, reads, threads=1, **opts):
     return secs, int(cells.value), scores
 
 
-def cpu_bench_sam(targets, reads, threads=1, name_base=0, **opts):
-    """bench.py cpu_baseline leg with the reference's worker model (`threads` workers, one aligner set each, chunks of 10
-    records): (seconds, cells, scores, [SAM text per read]) — records of read r are named read_%07d % (name_base + r)."""
+def cpu_bench_sam(targets, reads, threads=1, name_base=0, chunk=1, warm=1, **opts):
+    """bench.py cpu_baseline leg with the reference's worker model (`threads` workers, one aligner set each, `chunk` records
+    per pull), WARM: every worker builds its aligner set and aligns `warm` read(s) before the clock starts, and the clock
+    stops before anything is freed.  Returns (seconds, cells, scores, [SAM text per read], [busy seconds per worker]) — records
+    of read r are named read_%07d % (name_base + r)."""
     o, f = options_arrays(**opts)
     names, seqs, lens, keep = _targets(targets)
     cat = b"".join(reads)
@@ -288,15 +290,18 @@ def cpu_bench_sam(targets, reads, threads=1, name_base=0, **opts):
     rb = (C.c_uint8 * max(1, len(cat))).from_buffer_copy(cat or b"\0")
     cells = C.c_uint64(0)
     scores = np.zeros(len(reads), dtype=np.int64)
+    busy = np.zeros(max(1, int(threads)), dtype=np.float64)
     cap = (4 << 20) * max(1, len(reads)) + 64 * len(cat)          # (a chimeric read yields a record per segment, each with SEQ, QUAL and SA)
     buf = C.create_string_buffer(cap)
     soffs = np.zeros(len(reads) + 1, dtype=np.uint64)
-    secs = lib().orc_bench_sam(o, f, C.c_size_t(len(targets)), names, seqs, lens, rb,
-                               offs.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(len(reads)), int(threads),
-                               C.byref(cells), scores.ctypes.data_as(C.POINTER(C.c_int64)), C.c_size_t(name_base), buf,
-                               C.c_size_t(cap), soffs.ctypes.data_as(C.POINTER(C.c_uint64)))
+    fn = lib().orc_bench_warm
+    fn.restype = C.c_double
+    secs = fn(o, f, C.c_size_t(len(targets)), names, seqs, lens, rb,
+              offs.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(len(reads)), int(threads), int(chunk), int(warm),
+              C.byref(cells), scores.ctypes.data_as(C.POINTER(C.c_int64)), busy.ctypes.data_as(C.POINTER(C.c_double)),
+              C.c_size_t(name_base), buf, C.c_size_t(cap), soffs.ctypes.data_as(C.POINTER(C.c_uint64)))
     if int(soffs[-1]) > cap:
         raise RuntimeError("SAM buffer too small")
     raw = buf.raw
     sam = [raw[int(soffs[k]):int(soffs[k + 1])].decode() for k in range(len(reads))]
-    return secs, int(cells.value), scores, sam
+    return secs, int(cells.value), scores, sam, [float(b) for b in busy]

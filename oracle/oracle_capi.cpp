@@ -195,50 +195,65 @@ long orc_al_format_sam(void* hh, const char* head, const uint8_t* bases, size_t 
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 
-// CPU baseline leg (bench.py only): align `n_reads` reads with `threads` worker threads, each owning its own
-// Aligners (one aligner set per thread, fg-stitch-cli/src/commands/align.rs:345-390).  Returns wall seconds;
-// cells_out = sum of DP cells filled.
-double orc_bench_sam(const int32_t* opts, const float* fopts, size_t n_targets, const char* const* names,
-                     const uint8_t* const* seqs, const size_t* lens, const uint8_t* reads, const uint64_t* offsets,
-                     size_t n_reads, int threads, uint64_t* cells_out, int64_t* scores_out,
-                     size_t name_base, char* sam_buf, size_t sam_cap, uint64_t* sam_offsets);
-double orc_bench(const int32_t* opts, const float* fopts, size_t n_targets, const char* const* names,
-                 const uint8_t* const* seqs, const size_t* lens, const uint8_t* reads, const uint64_t* offsets,
-                 size_t n_reads, int threads, uint64_t* cells_out, int64_t* scores_out) {
-    return orc_bench_sam(opts, fopts, n_targets, names, seqs, lens, reads, offsets, n_reads, threads, cells_out, scores_out, 0, nullptr, 0, nullptr);
-}
-// The same with the worker model of fg-stitch-cli/src/commands/align.rs:345-390 spelled out: `threads` workers, each with its
-// own aligner set, pulling chunks of 10 records (align/io.rs:178-245), and the SAM text of every read (records '\n'-joined,
-// header line "read_%07zu" numbered from name_base, qualities all 'I') written to sam_buf at sam_offsets[r]..sam_offsets[r+1]
-// AFTER the clock has stopped (formatting runs on the reference's single writer thread and is not part of the aligners' time).
-double orc_bench_sam(const int32_t* opts, const float* fopts, size_t n_targets, const char* const* names,
-                     const uint8_t* const* seqs, const size_t* lens, const uint8_t* reads, const uint64_t* offsets,
-                     size_t n_reads, int threads, uint64_t* cells_out, int64_t* scores_out,
-                     size_t name_base, char* sam_buf, size_t sam_cap, uint64_t* sam_offsets) {
+// CPU baseline leg (bench.py only): the worker model of fg-stitch-cli/src/commands/align.rs:345-390 — `threads` workers, each
+// owning its own aligner set (one Aligners per thread; its traceback matrices are allocated once and re-initialised per read,
+// align/traceback/mod.rs:93-126), pulling chunks of `chunk` records (the reference: 10, align/io.rs:178-245; a bounded sample
+// uses 1 so that the workers stay balanced).
+//
+// WARM measurement: every worker first builds its aligner set and aligns `warm` read(s) of the sample outside the clock (the
+// first touch of its matrices: page faults and mm-lock contention are a property of a fresh process, not of the aligner in
+// steady state); the clock starts when all workers are ready and stops when the last one has finished its last read — before
+// any aligner set is freed.  Returns wall seconds; cells_out = DP cells filled inside the clock; busy_secs[t] (optional) =
+// each worker's own time inside the clock; scores_out[r] = score of the first chain.  SAM text (records '\n'-terminated, header
+// "read_%07zu" numbered from name_base, qualities all 'I') goes to sam_buf at sam_offsets[r]..sam_offsets[r+1] AFTER the clock
+// has stopped (formatting runs on the reference's single writer thread and is not part of the aligners' time).
+double orc_bench_warm(const int32_t* opts, const float* fopts, size_t n_targets, const char* const* names,
+                      const uint8_t* const* seqs, const size_t* lens, const uint8_t* reads, const uint64_t* offsets,
+                      size_t n_reads, int threads, int chunk, int warm, uint64_t* cells_out, int64_t* scores_out, double* busy_secs,
+                      size_t name_base, char* sam_buf, size_t sam_cap, uint64_t* sam_offsets) {
+    if (threads < 1) threads = 1;
+    if (chunk < 1) chunk = 1;
     std::atomic<size_t> next{0};
     std::atomic<uint64_t> cells{0};
+    std::atomic<int> ready{0}, done{0};
+    std::atomic<bool> go{false}, release{false};
     std::vector<std::vector<Alignment>> all_chains(n_reads);
     Options o = get_options(opts, fopts);
-    auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; ++t) {
-        pool.emplace_back([&]() {
+        pool.emplace_back([&, t]() {
             auto* h = (OrcAligners*)orc_al_new(opts, fopts, n_targets, names, seqs, lens);
+            for (int w = 0; w < warm && n_reads > 0; ++w) {
+                const size_t r = ((size_t)t + (size_t)w * (size_t)threads) % n_reads;
+                (void)h->al.align(reads + offsets[r], (size_t)(offsets[r + 1] - offsets[r]));
+            }
+            const uint64_t cells_warm = h->al.multi_contig.cells_filled;
+            ready.fetch_add(1);
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+            auto b0 = std::chrono::steady_clock::now();
             for (;;) {
-                const size_t r0 = next.fetch_add(10);
+                const size_t r0 = next.fetch_add((size_t)chunk);
                 if (r0 >= n_reads) break;
-                for (size_t r = r0; r < std::min(n_reads, r0 + 10); ++r) {
+                for (size_t r = r0; r < std::min(n_reads, r0 + (size_t)chunk); ++r) {
                     h->chains = h->al.align(reads + offsets[r], (size_t)(offsets[r + 1] - offsets[r]));
                     if (scores_out) scores_out[r] = h->chains.empty() ? 0 : h->chains[0].score;
                     if (sam_buf) all_chains[r] = h->chains;
                 }
             }
-            cells += h->al.multi_contig.cells_filled;
+            if (busy_secs) busy_secs[t] = std::chrono::duration<double>(std::chrono::steady_clock::now() - b0).count();
+            cells += h->al.multi_contig.cells_filled - cells_warm;
+            done.fetch_add(1);
+            while (!release.load(std::memory_order_acquire)) std::this_thread::yield();      // (freeing 16-byte matrices is not aligner time)
             delete h;
         });
     }
-    for (auto& th : pool) th.join();
+    while (ready.load() < threads) std::this_thread::yield();
+    auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    while (done.load() < threads) std::this_thread::sleep_for(std::chrono::microseconds(200));
     auto t1 = std::chrono::steady_clock::now();
+    release.store(true, std::memory_order_release);
+    for (auto& th : pool) th.join();
     if (cells_out) *cells_out = cells.load();
     if (sam_buf && sam_offsets) {
         auto* h = (OrcAligners*)orc_al_new(opts, fopts, n_targets, names, seqs, lens);
@@ -260,6 +275,12 @@ double orc_bench_sam(const int32_t* opts, const float* fopts, size_t n_targets, 
         delete h;
     }
     return std::chrono::duration<double>(t1 - t0).count();
+}
+// (kept for callers that only want a number: warm, one record per pull)
+double orc_bench(const int32_t* opts, const float* fopts, size_t n_targets, const char* const* names,
+                 const uint8_t* const* seqs, const size_t* lens, const uint8_t* reads, const uint64_t* offsets,
+                 size_t n_reads, int threads, uint64_t* cells_out, int64_t* scores_out) {
+    return orc_bench_warm(opts, fopts, n_targets, names, seqs, lens, reads, offsets, n_reads, threads, 1, 1, cells_out, scores_out, nullptr, 0, nullptr, 0, nullptr);
 }
 
 }  // extern "C"

@@ -1,0 +1,60 @@
+#!/bin/bash
+# The shader clock the fill kernel actually runs at, three ways, in ONE file (profiles/<tag>_clock.txt):
+#   1. inside the kernel: s_memtime (shader cycles) against s_memrealtime (100 MHz) over each launch's column loop
+#      (fill_regs.hip -> stitch_timing.clk_*; bench.py prints it as roofline.clock.in_kernel_mhz)
+#   2. rocm-smi sclk / socket power, sampled every 0.5 s while bench.py runs (the run's steady-state rows are the ones above 500 W)
+#   3. PMC of the same launch: GRBM_GUI_ACTIVE / 8 XCDs / t, SQ_WAVE_CYCLES x 4 / waves / t, SQ_BUSY_CYCLES / 32 / t
+#      (profiles/<tag>_pmc_fill.json must exist: run profiles/collect.sh <tag> first; profiled runs clock lower than plain ones)
+#   bash profiles/clock_probe.sh r03_a
+set -o pipefail
+tag=${1:-r03_x}
+out=gpurun_out/clock_$tag
+mkdir -p "$out"
+( while true; do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Socket Graphics Package Power" | tr '\n' ' '; echo; sleep 0.5; done ) > "$out/smi.txt" &
+smi_pid=$!
+python3 bench.py --steps 6 --warmup 2 --cpu-reads 0 > "$out/bench.json" 2> "$out/bench.err"
+rc=$?
+kill $smi_pid 2>/dev/null; wait $smi_pid 2>/dev/null
+[ $rc -eq 0 ] || { echo "bench failed"; tail -5 "$out/bench.err"; exit 1; }
+python3 - "$out" "$tag" <<'PY'
+import json, os, re, sys
+out, tag = sys.argv[1], sys.argv[2]
+here = "profiles"
+b = json.loads([l for l in open(os.path.join(out, "bench.json")) if l.startswith("{")][0])
+rf = b["roofline"]
+lines = [f"# shader clock of {rf['kernel']} on {b['device']['name']} ({tag}); bench: {b['value']:.1f} reads/s, {rf['avg_launch_ms']:.2f} ms per fill launch",
+         "", "1. in-kernel (s_memtime / s_memrealtime over the column loop, every launch of the timed steps):",
+         f"   {rf.get('clock', {}).get('in_kernel_mhz', float('nan')):.0f} MHz", "",
+         "2. rocm-smi while the bench ran (0.5 s samples; sclk MHz, socket power W):"]
+rows = []
+for l in open(os.path.join(out, "smi.txt")):
+    m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\).*Power \(W\): ([\d.]+)", l)
+    if m:
+        rows.append((int(m.group(1)), float(m.group(2))))
+busy = [r for r in rows if r[1] >= 500.0]
+lines.append("   all samples: " + " ".join(f"{c}/{int(p)}" for c, p in rows))
+if busy:
+    lines.append(f"   under load (>= 500 W, {len(busy)} samples): sclk {min(c for c, _ in busy)}-{max(c for c, _ in busy)} MHz, mean {sum(c for c, _ in busy) / len(busy):.0f}; "
+                 f"power {min(p for _, p in busy):.0f}-{max(p for _, p in busy):.0f} W, mean {sum(p for _, p in busy) / len(busy):.0f}")
+lines += ["", "3. PMC of the profiled launch (lower clock than an unprofiled run: MI355X_MICROARCH.md, DVFS give-back):"]
+p = os.path.join(here, f"{tag}_pmc_fill.json")
+if os.path.exists(p):
+    d = json.load(open(p)); k = d.get(rf["kernel"], {})
+    stats = os.path.join(here, f"{tag}_kernel_stats_fill.csv")
+    t = None
+    if os.path.exists(stats):
+        for l in open(stats):
+            if "fill_regs_kernel" in l:
+                t = float(l.rsplit('",', 1)[1].split(",")[2]) * 1e-6
+    waves = d.get("cells_per_launch", 0) / (b["config"]["cells_per_read"]) * 50 if d.get("cells_per_launch") else None
+    if t:
+        lines.append(f"   launch duration (kernel trace): {t * 1e3:.2f} ms; waves per launch: {waves:.0f}")
+        if "GRBM_GUI_ACTIVE" in k: lines.append(f"   GRBM_GUI_ACTIVE / 8 / t      = {k['GRBM_GUI_ACTIVE']['avg_per_launch_raw'] / 8 / t / 1e6:.0f} MHz")
+        if "SQ_WAVE_CYCLES" in k and waves: lines.append(f"   SQ_WAVE_CYCLES x 4 / waves / t = {k['SQ_WAVE_CYCLES']['avg_per_launch_raw'] * 4 / waves / t / 1e6:.0f} MHz   (quad-cycles; every wave lives the whole launch)")
+        if "SQ_BUSY_CYCLES" in k: lines.append(f"   SQ_BUSY_CYCLES / 32 / t       = {k['SQ_BUSY_CYCLES']['avg_per_launch_raw'] / 32 / t / 1e6:.0f} MHz   (if the counter is one per shader engine: 8 XCDs x 4)")
+else:
+    lines.append("   (no profiles/%s_pmc_fill.json)" % tag)
+open(os.path.join(here, f"{tag}_clock.txt"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(out, f"{tag}_clock.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+PY

@@ -12,7 +12,7 @@ out=gpurun_out/collect_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$out/trace" -o run --output-format csv -- python3 bench.py --cpu-reads 0 > "$out/trace.log" 2>&1 || { echo "trace failed"; exit 1; }
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS"; do
+for grp in "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS"; do
   d="$out/pmc_$(echo $grp | tr ' ' '_' | cut -c1-40)"
   rocprofv3 --pmc $grp -d "$d" -o run --output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-reads 0 > "$d.log" 2>&1 || { echo "pmc $grp failed"; exit 1; }
   echo "pmc $grp done" >> "$out/progress.txt"

@@ -374,6 +374,9 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
     int32_t MW1v = MW + 1, XW1v = XW + 1; asm volatile("" : "+v"(MW1v), "+v"(XW1v));
     uint32_t ychunk = 0;
     RPROF_DECL
+    // the shader clock this kernel actually gets: s_memtime (shader cycles) against s_memrealtime (100 MHz) over the column loop of
+    // each read's first wave, left behind the error word for the host (stitch_timing.clk_*; profiles/clock_probe.sh)
+    const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
     for (uint32_t j = 1; j <= n; ++j) {
         const bool lastcol = j == n;
         RPROF(7)
@@ -398,7 +401,12 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                     }
                 }
                 if (__all(ok)) break;
-                if ((spins & 1023u) == 0 && (uint32_t)wall_clock64() - t0 > 400000000u) { if (lane == 0) *V.err = 1; return; }      // 4 s at 100 MHz: a partner is not resident
+                if ((spins & 1023u) == 0) {
+                    // 4 s at 100 MHz: a partner is not resident — or another wave of the read has said so already (its error word, read
+                    // at agent scope: a workgroup that becomes resident late does not wait its own four seconds)
+                    const uint32_t e_seen = __builtin_amdgcn_raw_buffer_load_b32(rxc, 0u, 32u * C, AUX_SC1 | AUX_VOLATILE);
+                    if (e_seen != 0u || (uint32_t)wall_clock64() - t0 > 400000000u) { if (lane == 0) *V.err = 1; return; }
+                }
                 __builtin_amdgcn_s_sleep(STITCH_POLL_SLEEP);
             }
             uint32_t best = 0;
@@ -676,6 +684,10 @@ __global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restric
                 Lx[(size_t)c * (n + 1) + j] = lx;
             }
         }
+    }
+    if (kmine == 0 && lane == 0) {
+        unsigned long long* const ck = (unsigned long long*)((uint8_t*)V.err + ERR_CLOCK_OFF);
+        ck[0] = __builtin_readcyclecounter() - clk_c0; ck[1] = wall_clock64() - clk_w0;
     }
     // ---- column n's arrays for the fix-up kernel (single_contig_aligner.rs:453-555): the final words, and the insertion chain at
     // every row — recomputed here from the final words (an opener taken from a merged cell gives the same chain, see above)

@@ -733,6 +733,10 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             static const char* nm[8] = {"gather/loop", "select", "barrier1", "slot-setup", "tile", "finalize", "tile_wait", "barrier2"};
             for (int w = 0; w < waves; ++w) { fprintf(stderr, "[prof] wave %d:", w); for (int k = 0; k < 8; ++k) { if (k == 2) fprintf(stderr, " tiles=%llu merged=%llu", pf[w * 8 + 2] >> 32, pf[w * 8 + 2] & 0xFFFFFFFFull); else if (k == 1) fprintf(stderr, " simd=%u slot=%u cu=%u", (unsigned)((pf[w * 8 + 1] >> 4) & 3), (unsigned)(pf[w * 8 + 1] & 15), (unsigned)((pf[w * 8 + 1] >> 8) & 15)); else fprintf(stderr, " %s=%.1fM", nm[k], pf[w * 8 + k] / 1e6); } fprintf(stderr, "\n"); }
         }
+        if (kind == 2u) {      // the shader clock the fill got (fill_regs.hip leaves it behind the first read's error word)
+            unsigned long long ck[2] = {0, 0}; HIP_TRY(hipMemcpy(ck, (const uint8_t*)views[0].err + ERR_CLOCK_OFF, sizeof(ck), hipMemcpyDeviceToHost));
+            c.tm.clk_shader_cycles += ck[0]; c.tm.clk_ref_ticks += ck[1];
+        }
         bool timed_out = false;
         if (kind != 0u) for (uint32_t q = 0; q < nj; ++q) {
             uint32_t e = 0; HIP_TRY(hipMemcpy(&e, views[q].err, 4, hipMemcpyDeviceToHost));
@@ -746,11 +750,15 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             bool one_table = true;
             for (uint32_t q = 0; q < nj; ++q) if (local16_wg_tiles(c, jobs[k0 + q], 1) > fill_local16_max_slots()) one_table = false;
             kind = one_table ? 1u : 0u; G = 1; slots_cap = 0;
+            // (the wave count is worked out afresh for the kernel that runs now: what the first attempt chose may exceed the generic
+            // kernel's launch bounds)
+            waves = 1;
             for (uint32_t q = 0; q < nj; ++q) {
                 slots_cap = std::max(slots_cap, local16_wg_tiles(c, jobs[k0 + q], 1));
                 views[q].tb_keyfmt = kind; waves = std::max(waves, pick_waves(c, lay[k0 + q].nact, MAX_WAVES_GENERIC));
                 HIP_TRY(hipMemsetAsync(c.arena + base[q] + lay[k0 + q].off_xchg, 0, 32ull * c.C + 4096, c.stream));
             }
+            waves = std::min(waves, MAX_WAVES_GENERIC);
             if (kind == 1u) waves = MAX_WAVES_LOCAL;
             HIP_TRY(hipMemcpyAsync(d_views, views.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, c.stream));
             c.tm.fill_kind = kind; c.tm.wg_per_read = 1; c.tm.fallbacks += 1;

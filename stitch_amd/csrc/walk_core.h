@@ -24,6 +24,7 @@ struct ChainHdr {              // == Alignment (align/alignment.rs:16-51)
     uint32_t start_contig_idx, end_contig_idx, length, n_ops, status;   // status: 0 ok, 1 None, 2 overflow, 3 bad move / runaway, 4 reference-undefined XJUMP
 };
 
+constexpr uint32_t ERR_CLOCK_OFF = 3072;   // behind JobView::err: {shader cycles, 100 MHz ticks} of the read's column loop (fill_regs.hip)
 constexpr int REGS_RMAX = 80;  // fill_regs.hip: rows a lane holds in registers (a wave owns one contig of up to 64 x REGS_RMAX rows)
 
 struct JobView {

@@ -25,7 +25,7 @@ def test_bench_refuses_to_run_without_a_gpu():
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
     r = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--reads-per-step", "6", "--read-len", "500", "--contigs", "4",
-                  "--contig-len", "700", "--cpu-reads", "3", "--cpu-prefix", "200", "--cpu-threads", "2")
+                  "--contig-len", "700", "--cpu-reads-per-worker", "2", "--cpu-prefix", "200", "--cpu-threads", "2")
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -39,7 +39,8 @@ def test_bench_line_has_the_contract_fields():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel"] in ("stitch::fill_local16_kernel", "stitch::fill_regs_kernel")
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 2 and cb["value"] > 0 and cb["unit"] == "reads/s" and cb["sample"]
-    assert cb["sam_identical_on_sample"] is True and cb["sam_reads_compared"] == 3
+    assert cb["sam_identical_on_sample"] is True and cb["sam_reads_compared"] == 4      # two timed reads per worker
+    assert cb["warm"] is True and [x["threads"] for x in cb["scaling"]] == [1, 2] and cb["mcells_per_sec_per_thread"] > 0
 
 
 @pytest.mark.gpu

@@ -306,3 +306,17 @@ def test_more_tiles_than_one_workgroup_slot_table_holds():
     al = run_pair(targets, reads, double_strand=True, check_sam=False)
     tm = al.timing()
     assert tm["fill_kind"] == 1 and tm["wg_per_read"] >= 6 and tm["fallbacks"] == 0, tm
+
+
+def test_partner_timeout_on_a_read_beyond_one_slot_table_falls_back_to_the_generic_kernel(monkeypatch):
+    """The same database with the first attempt declared timed out (test hook): one workgroup per read cannot hold 10 240 tiles in
+    its slot table, so the repeat runs the generic kernel — with a wave count worked out for THAT kernel (the streaming kernel's
+    12 waves exceed its launch bounds: the relaunch used to be rejected)."""
+    monkeypatch.setenv("STITCH_TEST_FAIL_FIRST_ATTEMPT", "1")
+    rng = random.Random(78)
+    targets = [(f"big{k}", rand_seq(rng, 10000)) for k in range(128)]
+    reads = [chimera(rng, targets[:40], 50, err=0.03, both=True) for _ in range(2)]
+    al = run_pair(targets, reads, double_strand=True, check_sam=False)
+    tm = al.timing()
+    assert tm["fill_kind"] == 0 and tm["fallbacks"] >= 1 and tm["wg_per_read"] == 1, tm
+

@@ -20,12 +20,23 @@ def every_eligible_read_to_the_register_kernel(monkeypatch):
     monkeypatch.setenv("STITCH_REGS_MIN_ROWS", "0")
 
 
-def test_the_register_kernel_is_the_one_that_runs():
-    db = synth.make_db(5, 700, 3)
+def test_the_register_kernel_is_the_one_that_runs(monkeypatch):
+    """1400 contig rows: BELOW the default threshold of 2048, so fill_kind == 2 here proves that the fixture above is what sends
+    this module's small cases to the register kernel — and the same database without it runs the streaming kernel."""
+    db = synth.make_db(2, 700, 3)
     al = stitch_amd.Builder().build_aligners([stitch_amd.TargetSeq(n, s) for n, s in db])
     al.align(synth.make_reads(db, 4, 300, 5))
     tm = al.timing()
+    assert tm["fill_kind"] == 2 and tm["wg_per_read"] == 1          # 2 contigs: one workgroup of four waves
+    db5 = synth.make_db(5, 700, 3)
+    al5 = stitch_amd.Builder().build_aligners([stitch_amd.TargetSeq(n, s) for n, s in db5])
+    al5.align(synth.make_reads(db5, 4, 300, 5))
+    tm = al5.timing()
     assert tm["fill_kind"] == 2 and tm["wg_per_read"] == 2          # 5 contigs: two workgroups of four waves
+    monkeypatch.delenv("STITCH_REGS_MIN_ROWS")
+    al_default = stitch_amd.Builder().build_aligners([stitch_amd.TargetSeq(n, s) for n, s in db])
+    al_default.align(synth.make_reads(db, 4, 300, 5))
+    assert al_default.timing()["fill_kind"] == 1                    # default threshold: small reads stream
 
 
 def test_golden_single_contig():
