@@ -34,7 +34,7 @@ namespace {
 
 constexpr int RMAX = REGS_RMAX;                // rows per lane (walk_core.h: the traceback layout depends on it)
 constexpr int NG = RMAX / 4;                   // groups of four rows: one traceback dword, one word of bases
-static_assert(RMAX == 80, "the group blocks below are written out for 20 groups");
+static_assert(RMAX == 80 || RMAX == 40, "the group blocks below are written out for 20 (or, in experiment builds, 10) groups");
 constexpr uint32_t RSRC_WORD3 = 0x00020000u;   // raw buffer descriptor, gfx94x / gfx950
 constexpr int AUX_NT = 2;                      // streamed once: non-temporal
 constexpr int AUX_SC1 = 16;                    // agent-scope coherence (what an agent-scope atomic load carries on gfx94x / gfx950)
@@ -229,13 +229,20 @@ __device__ __forceinline__ void group_records(Recs& R, const uint32_t g4, const 
     R.bw = g4 > R.bw ? g4 : R.bw;
 }
 
+#if STITCH_REGS_RMAX == 80
 #define REP20(X) X(19) X(18) X(17) X(16) X(15) X(14) X(13) X(12) X(11) X(10) X(9) X(8) X(7) X(6) X(5) X(4) X(3) X(2) X(1) X(0)
+#else
+#define REP20(X) X(9) X(8) X(7) X(6) X(5) X(4) X(3) X(2) X(1) X(0)
+#endif
+#ifndef STITCH_REGS_WAVES_PER_EU
+#define STITCH_REGS_WAVES_PER_EU 2
+#endif
 
 }  // namespace
 
 // NQ = granule registers per lane: 1 for up to 64 active contigs, 4 for up to 256
 template <int NQ, bool CIRC>
-__global__ __launch_bounds__(512) void fill_regs_kernel(const JobView* __restrict__ jobs, FillShared sh, uint32_t G) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS_WAVES_PER_EU, STITCH_REGS_WAVES_PER_EU))) void fill_regs_kernel(const JobView* __restrict__ jobs, FillShared sh, uint32_t G) {
     // (the quotient comes out of vector arithmetic: tell the compiler it is uniform, so that everything read through V is scalar)
     const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / G));
     const JobView& V = jobs[job];

@@ -25,7 +25,10 @@ struct ChainHdr {              // == Alignment (align/alignment.rs:16-51)
 };
 
 constexpr uint32_t ERR_CLOCK_OFF = 3072;   // behind JobView::err: {shader cycles, 100 MHz ticks} of the read's column loop (fill_regs.hip)
-constexpr int REGS_RMAX = 80;  // fill_regs.hip: rows a lane holds in registers (a wave owns one contig of up to 64 x REGS_RMAX rows)
+#ifndef STITCH_REGS_RMAX
+#define STITCH_REGS_RMAX 80     // (experiment builds: 40 rows per lane at three waves per SIMD)
+#endif
+constexpr int REGS_RMAX = STITCH_REGS_RMAX;  // fill_regs.hip: rows a lane holds in registers (a wave owns one contig of up to 64 x REGS_RMAX rows)
 
 struct JobView {
     DpParams P;

@@ -16,7 +16,7 @@ def run_bench(*args):
 
 def test_bench_refuses_to_run_without_a_gpu():
     import torch
-    if torch.cuda.is_available():
+    if torch.cuda.is_available() or os.path.exists("/dev/kfd"):
         pytest.skip("a GPU is present")
     r = run_bench("--steps", "1", "--warmup", "0")
     assert r.returncode != 0 and b"needs a GPU" in r.stderr + r.stdout
