@@ -37,7 +37,7 @@ SHADER_CLOCK_HZ = 2.4e9    # MI355X_MICROARCH.md "Chip-level parameters": max cl
 # measured on this chip (profiles/ubench/valu_issue.hip -> valu_issue_mi355x.txt: 4.1-4.4 cycles with 2-4 waves, 4.9 with one).
 # MI355X_MICROARCH.md's 2 cycles (SIMD-32) is the v_fma_f32 figure; the integer instructions of the fill do not get it.
 VALU_CYCLES_PER_WAVE_INST = 4.0
-FILL_KERNELS = {0: "stitch::fill_kernel", 1: "stitch::fill_local16_kernel", 2: "stitch::fill_regs_kernel"}      # stitch_timing.fill_kind
+FILL_KERNELS = {0: "stitch::fill_kernel", 1: "stitch::fill_local16_kernel", 2: "stitch::fill_regs_kernel", 3: "stitch::fill_regs32_kernel"}      # stitch_timing.fill_kind
 KERNEL_SOURCES = ("fill_local16.hip", "fill_regs.hip", "dp_core.h", "walk_core.h", "stitch_api.cpp")
 
 

@@ -99,7 +99,7 @@ long stitch_format_sam(stitch_ctx*, uint32_t read_idx, const char* head, const u
 typedef struct stitch_timing { double fill_ms, walk_ms, h2d_ms, d2h_ms, host_ms; uint64_t cells; uint32_t launches; uint32_t jobs;
                                double prealign_ms /* banded kernels incl. their transfers */, prealign_host_ms /* seeds, backbone, band: runs on host
                                   threads concurrently with prealign_ms of the chunk before, so the two overlap */;
-                               uint32_t fill_kind /* kernel of the last fill launch: 0 generic int32, 1 Local-mode streaming, 2 Local-mode register-resident */,
+                               uint32_t fill_kind /* kernel of the last fill launch: 0 generic int32, 1 Local-mode streaming, 2 Local-mode register-resident, 3 register-resident 32-bit (every mode, long reads) */,
                                         wg_per_read /* workgroups that shared one read in that launch */,
                                         fallbacks /* launches repeated with one workgroup per read after a partner timeout */, pad_;
                                uint64_t clk_shader_cycles, clk_ref_ticks /* register-resident fill only: shader cycles (s_memtime) and 100 MHz ticks

@@ -262,7 +262,7 @@ struct WaveWalk {
             const ContigDesc d = V.cd[cur];
             const uint32_t ii = i - l, jj = j - l;
             const uint32_t raw = V.tb[(size_t)(jj - 1) * V.Rtot + d.roff + tb_row_offset(V.tb_keyfmt, d, ii)];
-            const uint32_t code = V.tb_keyfmt ? key_code_to_generic(raw, false) : raw;
+            const uint32_t code = (V.tb_keyfmt == 1 || V.tb_keyfmt == 2) ? key_code_to_generic(raw, false) : raw;
             ok = (code & 7u) == MV_DIAG;
             match = V.xseq[d.seqoff + ii - 1] == V.y[jj - 1];
         }

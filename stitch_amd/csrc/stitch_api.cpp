@@ -48,6 +48,9 @@ uint32_t fill_local16_max_slots();
 void launch_fill_regs(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
 uint32_t fill_regs_rows_per_wave();
 int fill_regs_workgroups_per_cu(uint32_t waves);
+void launch_fill_regs32(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
+uint32_t fill_regs32_rows_per_wave();
+int fill_regs32_workgroups_per_cu();
 }  // namespace stitch
 
 using namespace stitch;
@@ -76,8 +79,9 @@ struct Job {                                     // one full jump DP
 // Diagnostic / experiment knobs, read from the environment ONCE when a context is created (never per launch).
 struct Knobs {
     bool fail_first_attempt = false;             // test hook: treat the first attempt of every cooperative launch as timed out
-    bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false;
+    bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false, no_regs32 = false, force_regs32 = false;
     size_t array_align = 0, job_align = 0;
+    std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
     static Knobs from_env() {
         Knobs k;
@@ -87,6 +91,9 @@ struct Knobs {
         k.fail_first_attempt = getenv("STITCH_TEST_FAIL_FIRST_ATTEMPT") != nullptr;
         k.fill_only = getenv("STITCH_EXP_FILL_ONLY") != nullptr;      // experiment builds whose results are garbage: time the fill, skip the walk
         k.no_regs = getenv("STITCH_NO_REGS") != nullptr;             // keep the state-streaming kernel even where the register-resident one applies
+        k.no_regs32 = getenv("STITCH_NO_REGS32") != nullptr;         // keep the generic kernel where the 32-bit register-resident one applies
+        k.force_regs32 = getenv("STITCH_FORCE_REGS32") != nullptr;   // (tests) the 32-bit register-resident kernel also where a 16-bit Local-mode kernel applies
+        if (const char* e = getenv("STITCH_DUMP_DIR")) k.dump_dir = e;
         k.array_align = (size_t)num("STITCH_ARRAY_ALIGN"); k.job_align = (size_t)num("STITCH_JOB_ALIGN");
         k.max_waves = (int)num("STITCH_MAX_WAVES"); k.wg_per_read = (int)num("STITCH_WG_PER_READ"); k.tiles_per_wave = (int)num("STITCH_TILES_PER_WAVE");
         if (const char* e = getenv("STITCH_REGS_MIN_ROWS")) k.regs_min_rows = atol(e);     // (tests: 0 sends every eligible read to fill_regs.hip)
@@ -122,6 +129,7 @@ struct stitch_ctx {
     stitch_timing tm{};
     int n_cus = 256; uint32_t tm_wg_per_read = 1;
     int regs_wg_per_cu = 0;                      // workgroups of fill_regs.hip one CU holds at once (occupancy query; 0: kernel unusable)
+    int regs32_wg_per_cu = 0;                    // ... of fill_regs32.hip (one: a wave takes a SIMD's whole register file)
     bool tm_fast = false;                        // last run_jobs used the Local-mode 16-bit kernel
     size_t mem_limit = 0;                        // optional cap on arena bytes (STITCH_ARENA_BYTES), for tests
     // banded pre-alignment filter (prealign.h): host copies of the contig strands, their k-mer indexes, device scratch
@@ -317,6 +325,7 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     if (const char* lim = getenv("STITCH_ARENA_BYTES")) c->mem_limit = (size_t)strtoull(lim, nullptr, 10);
     c->knobs = Knobs::from_env();
     c->regs_wg_per_cu = fill_regs_workgroups_per_cu(4);
+    c->regs32_wg_per_cu = fill_regs32_workgroups_per_cu();
     *out = c.release();
     return STITCH_OK;
 }
@@ -411,6 +420,32 @@ uint32_t regs_plan(const stitch_ctx& c, const Job& jb) {
     return G;
 }
 
+// The 32-bit register-resident kernel (fill_regs32.hip): every clipping mode, reads beyond the 16-bit kernels' range.  One wave per
+// active contig, four waves per workgroup, one workgroup per CU.  Returns the workgroups a read needs (0: not applicable).
+// Its arithmetic rests on every score the recurrence can produce staying a "real" number: |score| < 2^27, so that a candidate
+// that carries a MIN_SCORE clip penalty never wins and no cell reaches MIN_SCORE (fill_regs32.hip header).  Alignment lengths are
+// 16-bit: a chain's length = its read bases (<= n) + the contig bases it inserts — forced ones at the ends of an x-global
+// alignment (<= 2 max_m) and voluntary ones, each of which costs |gap_extend| out of a score budget of match * n.
+uint32_t regs32_plan(const stitch_ctx& c, const Job& jb) {
+    const stitch_opts& o = c.opts;
+    if (c.knobs.no_regs32 || c.knobs.force_generic || c.regs32_wg_per_cu <= 0) return 0;
+    const long long n = (long long)jb.y.size(), mm = (long long)c.max_m;
+    const long long big = std::max<long long>({std::llabs((long long)o.match_score), std::llabs((long long)o.mismatch_score), std::llabs((long long)o.gap_open) + std::llabs((long long)o.gap_extend),
+                                               std::llabs((long long)o.jump_same), std::llabs((long long)o.jump_opposite), std::llabs((long long)o.jump_inter)});
+    if (big > 4000 || big * (n + mm + 4) >= (1ll << 27)) return 0;      // (4000: the records' 16-bit relative scores, KEY_BIAS in fill_regs32.hip)
+    if (o.gap_extend >= 0 || o.gap_open > 0) return 0;
+    const long long forced = o.mode == 0 ? 0 : 2 * mm;
+    if (n + forced + (long long)std::max(o.match_score, 0) * n / (long long)(-o.gap_extend) + 2 > 65535) return 0;
+    if (n + mm + 2 > 65535) return 0;
+    uint64_t rows = 0;
+    for (uint32_t a : jb.act) { if (c.al[a].m > fill_regs32_rows_per_wave()) return 0; rows += c.al[a].m; }
+    const uint64_t min_rows = c.knobs.regs_min_rows >= 0 ? (uint64_t)c.knobs.regs_min_rows : 2048u;
+    if (rows < min_rows) return 0;
+    const uint32_t G = ((uint32_t)jb.act.size() + REGS_WAVES - 1) / REGS_WAVES;
+    if (G > (uint32_t)c.n_cus * (uint32_t)c.regs32_wg_per_cu) return 0;
+    return G;
+}
+
 constexpr int MAX_WAVES_GENERIC = 8;               // fill_kernel.hip: __launch_bounds__(512)
 #ifndef STITCH_LB
 #define STITCH_LB 768
@@ -485,6 +520,11 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         if (all_fast) for (const Job& jb : jobs) rg_min = std::min(rg_min, regs_plan(c, jb));
         size_t win = (all_fast && gd_min > 1) ? std::min<size_t>(jobs.size(), (size_t)std::max(1, c.n_cus) / gd_min) : jobs.size();
         if (all_fast && rg_min > 0 && rg_min != 0xFFFFFFFFu) win = std::min<size_t>(jobs.size(), std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs_wg_per_cu / rg_min));
+        if (!all_fast || c.knobs.force_regs32) {      // (the 32-bit register-resident kernel: one workgroup per CU, all workgroups of a launch resident)
+            uint32_t r32_min = 0xFFFFFFFFu;
+            for (const Job& jb : jobs) r32_min = std::min(r32_min, regs32_plan(c, jb));
+            if (r32_min > 0 && r32_min != 0xFFFFFFFFu) win = std::min<size_t>(jobs.size(), std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs32_wg_per_cu / r32_min));
+        }
         size_t cur = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
             cur += lay[k].stride + sizeof(JobView) + sizeof(WalkArgs) + 512;
@@ -533,8 +573,11 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         // workgroup's slot table holds 2048 tiles.
         size_t max_jobs = 4096;
         uint32_t g_min = 1;
-        const uint32_t regs_G = fast ? regs_plan(c, jobs[k0]) : 0u;       // > 0: this launch runs the register-resident kernel
+        const uint32_t regs_G = (fast && !c.knobs.force_regs32) ? regs_plan(c, jobs[k0]) : 0u;       // > 0: this launch runs the register-resident kernel
+        // the 32-bit register-resident kernel: where no 16-bit Local-mode kernel applies (other clipping modes, long reads)
+        const uint32_t regs32_G = (regs_G == 0 && (!fast || c.knobs.force_regs32)) ? regs32_plan(c, jobs[k0]) : 0u;
         if (regs_G) max_jobs = std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs_wg_per_cu / regs_G);      // every workgroup of the launch resident at once
+        else if (regs32_G) max_jobs = std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs32_wg_per_cu / regs32_G);
         else if (fast) {
             uint32_t tiles = 0; for (uint32_t a : jobs[k0].act) tiles += (c.al[a].m + 255) / 256;
             g_min = local16_min_g(c, jobs[k0]);
@@ -551,8 +594,8 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         const size_t per_job = sizeof(JobView) + sizeof(WalkArgs) + 512;     // the launch's job table, after the jobs' own buffers
         while (k1 < jobs.size() && used + lay[k1].stride + per_job + view_room <= c.arena_bytes && (k1 - k0) < max_jobs &&
-               (k1 == k0 || regs_plan(c, jobs[k1]) == regs_G || !fast)) {
-            if (fast && !regs_G && k1 > k0) {
+               (k1 == k0 || (regs32_G ? regs32_plan(c, jobs[k1]) == regs32_G : (regs_plan(c, jobs[k1]) == regs_G || !fast)))) {
+            if (fast && !regs_G && !regs32_G && k1 > k0) {
                 // a later job may need MORE workgroups than the first (shorter read, more contigs): all workgroups of the launch
                 // must still be resident at once
                 const uint32_t gk = local16_min_g(c, jobs[k1]);
@@ -601,7 +644,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             memcpy(stg + (L.off_cd - L.off_y), cd.data(), sizeof(ContigDesc) * (size_t)c.C);
             HIP_TRY(hipMemcpyAsync(B + L.off_y, stg, L.off_hdr - L.off_y, hipMemcpyHostToDevice, c.stream));
             JobView& V = views[q];
-            V.tb_keyfmt = regs_G ? 2u : fast ? 1u : 0u; V.yrec_global = jb.mode == 0 ? 1u : 0u;
+            V.tb_keyfmt = regs_G ? 2u : regs32_G ? 3u : fast ? 1u : 0u; V.yrec_global = jb.mode == 0 ? 1u : 0u;
             V.P = c.P; V.n = L.n; V.C = c.C; V.nact = L.nact; V.Rtot = L.Rj;
             V.act = (const uint32_t*)(B + L.off_act); V.opp_act = (const int32_t*)(B + L.off_opp); V.cd = (const ContigDesc*)(B + L.off_cd);
             V.xseq = c.d_xseq; V.y = B + L.off_y;
@@ -634,6 +677,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         // wait for each other every column) and leave each at least a couple of contigs
         uint32_t G = 1;
         if (regs_G) G = regs_G;
+        else if (regs32_G) G = regs32_G;
         else if (fast) {
             uint32_t min_act = 0xFFFFFFFFu;
             for (uint32_t q = 0; q < nj; ++q) min_act = std::min(min_act, lay[k0 + q].nact);
@@ -665,9 +709,9 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             waves = (int)std::max(1u, std::min<uint32_t>(MAX_WAVES_LOCAL, min_tiles / tpw));
             if (c.knobs.max_waves) waves = std::max(1, std::min(waves, c.knobs.max_waves));
         }
-        c.tm_wg_per_read = G; c.tm.wg_per_read = G; c.tm.fill_kind = regs_G ? 2u : fast ? 1u : 0u;
+        c.tm_wg_per_read = G; c.tm.wg_per_read = G; c.tm.fill_kind = regs_G ? 2u : regs32_G ? 3u : fast ? 1u : 0u;
         uint32_t slots_cap = 0;                          // tiles of the launch's largest workgroup (contigs are dealt round-robin to a read's G workgroups)
-        if (fast && !regs_G) for (uint32_t q = 0; q < nj; ++q) {
+        if (fast && !regs_G && !regs32_G) for (uint32_t q = 0; q < nj; ++q) {
             std::vector<uint32_t> per(G, 0);
             const std::vector<uint32_t>& act = jobs[k0 + q].act;
             for (size_t k = 0; k < act.size(); ++k) per[k % G] += (c.al[act[k]].m + 255) / 256;
@@ -677,9 +721,10 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         // at once.  The grid is sized for that, but another process on the device, CU masking or reserved CUs can break it: the
         // kernels then give up after a bounded wait (error word 1) and the launch is run ONCE more on the streaming kernel with one
         // workgroup per read (nothing waits across workgroups there), or on the generic kernel if a read's tiles exceed one slot table.
-        uint32_t kind = regs_G ? 2u : fast ? 1u : 0u;
+        uint32_t kind = regs_G ? 2u : regs32_G ? 3u : fast ? 1u : 0u;
         for (int attempt = 0;; ++attempt) {
-        if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, nj, G, REGS_WAVES, mx, c.opts.circular != 0, sh, c.stream); }
+        if (kind == 3u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs32(d_views, nj, G, mx, c.opts.circular != 0, sh, c.stream); }
+        else if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, nj, G, REGS_WAVES, mx, c.opts.circular != 0, sh, c.stream); }
         else if (kind == 1u) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, c.stream);
         else launch_fill(d_views, nj, waves, sh, c.stream);
         HIP_TRY(hipGetLastError());
@@ -690,6 +735,27 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             float ms_f = 0; HIP_TRY(hipEventElapsedTime(&ms_f, c.ev[0], c.ev[1])); c.tm.fill_ms += ms_f; c.tm.launches += 1; c.tm.jobs += nj;
             if (c.knobs.debug) fprintf(stderr, "[stitch] fill-only launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms\n", nj, G, waves, ms_f);
             break;
+        }
+        if (!c.knobs.dump_dir.empty()) {
+            // debugging aid: what the fill kernel hands to the fix-up kernel (rows of the active contigs in order, roff-indexed), so
+            // that two kernels can be compared array by array on the same job
+            HIP_TRY(hipStreamSynchronize(c.stream));
+            static int dump_no = 0;
+            for (uint32_t q = 0; q < nj; ++q) {
+                const JobLayout& L = lay[k0 + q]; const uint8_t* B = c.arena + base[q];
+                const std::string path = c.knobs.dump_dir + "/fill_" + std::to_string(dump_no++) + "_kind" + std::to_string(kind) + ".bin";
+                FILE* f = fopen(path.c_str(), "wb");
+                if (!f) continue;
+                const uint32_t hdr[4] = {L.n, L.nact, L.Rj, c.C};
+                fwrite(hdr, 4, 4, f);
+                std::vector<uint8_t> buf(4ull * L.Rj);
+                for (size_t off : {L.off_S, L.off_Slen, L.off_Ival, L.off_Ilen, L.off_Sn, L.off_SnLen, L.off_Ly}) { HIP_TRY(hipMemcpy(buf.data(), B + off, 4ull * L.Rj, hipMemcpyDeviceToHost)); fwrite(buf.data(), 1, buf.size(), f); }
+                std::vector<uint8_t> big(4ull * c.C * (L.n + 1));
+                for (size_t off : {L.off_Lx, L.off_jti, L.off_jtf}) { HIP_TRY(hipMemcpy(big.data(), B + off, big.size(), hipMemcpyDeviceToHost)); fwrite(big.data(), 1, big.size(), f); }
+                std::vector<ContigDesc> cds(c.C); HIP_TRY(hipMemcpy(cds.data(), B + L.off_cd, sizeof(ContigDesc) * c.C, hipMemcpyDeviceToHost));
+                for (const ContigDesc& d : cds) { const uint32_t v[2] = {d.m, d.roff}; fwrite(v, 4, 2, f); }
+                fclose(f);
+            }
         }
         uint32_t max_nact_mode1 = 0;
         for (uint32_t q = 0; q < nj; ++q) if (jobs[k0 + q].mode == 1) max_nact_mode1 = std::max(max_nact_mode1, lay[k0 + q].nact);
@@ -743,12 +809,12 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             if ((e & 0xFFu) == 2u) return fail(STITCH_EINTERNAL, "fill kernel bounds check failed, code " + std::to_string(e >> 8));
             if (e) timed_out = true;
         }
-        if (attempt == 0 && c.knobs.fail_first_attempt && (kind == 2u || G > 1)) timed_out = true;      // (test hook: exercises the relaunch)
+        if (attempt == 0 && c.knobs.fail_first_attempt && (kind >= 2u || G > 1)) timed_out = true;      // (test hook: exercises the relaunch)
         if (!timed_out) break;
         if (attempt > 0 || (kind == 1u && G == 1)) return fail(STITCH_EINTERNAL, "the fill kernel timed out waiting for a partner (workgroups of one read not co-resident, or a lost hand-off between waves)");
         {
-            bool one_table = true;
-            for (uint32_t q = 0; q < nj; ++q) if (local16_wg_tiles(c, jobs[k0 + q], 1) > fill_local16_max_slots()) one_table = false;
+            bool one_table = kind != 3u;      // (a launch of the 32-bit kernel holds reads no 16-bit kernel takes: the generic kernel repeats it)
+            for (uint32_t q = 0; q < nj; ++q) if (one_table && (!local16_ok(c, jobs[k0 + q]) || local16_wg_tiles(c, jobs[k0 + q], 1) > fill_local16_max_slots())) one_table = false;
             kind = one_table ? 1u : 0u; G = 1; slots_cap = 0;
             // (the wave count is worked out afresh for the kernel that runs now: what the first attempt chose may exceed the generic
             // kernel's launch bounds)

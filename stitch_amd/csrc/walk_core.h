@@ -33,7 +33,8 @@ constexpr int REGS_RMAX = STITCH_REGS_RMAX;  // fill_regs.hip: rows a lane holds
 struct JobView {
     DpParams P;
     uint32_t n, C, nact, Rtot;
-    uint32_t tb_keyfmt;        // 1: traceback bytes are in the Local-mode kernels' key format; 2: key format, lane-interleaved rows (fill_regs.hip)
+    uint32_t tb_keyfmt;        // 0: generic move codes, rows linear; 1: the Local-mode kernels' key format; 2: key format, lane-interleaved rows
+                               // (fill_regs.hip); 3: generic move codes, lane-interleaved rows (fill_regs32.hip)
     uint32_t yrec_global;      // fill_regs.hip: y-suffix records only for cells that reach the best score of ANY contig so far (mode traceback)
     const uint32_t* act;       // active aligner ids in aligner order (the reference's `self.contigs` after sub-setting)
     const int32_t* opp_act;    // [C] opposite-strand aligner id if both strands are active, else -1
@@ -92,7 +93,7 @@ STITCH_HD void decode_src(const JobView& V, uint32_t c, uint32_t i, uint32_t j, 
 // goes to byte ((idx >> 2) * 64 + l) * 4 + (idx & 3), so that one store instruction writes whole lines.
 STITCH_HD uint32_t tb_div_magic(uint32_t d) { return d ? (uint32_t)(0x100000000ull / d) + 1u : 0u; }      // exact quotients for n * d < 2^32
 STITCH_HD uint32_t tb_row_offset(uint32_t keyfmt, const ContigDesc& d, uint32_t i) {
-    if (keyfmt != 2) return i - 1;
+    if (keyfmt < 2) return i - 1;
     const uint32_t ngr = (d.m + 3) / 4, gq = ngr / 64, grem = ngr % 64, row = i - 1;
     const uint32_t big = 4 * (gq + 1), small = 4 * gq;
     uint32_t lane, uu, nrows;
@@ -107,7 +108,7 @@ STITCH_HD uint32_t tb_row_offset(uint32_t keyfmt, const ContigDesc& d, uint32_t 
 // and flags "row 1 took the circular jump" in bit 31 of the column's jump-table entry.
 STITCH_HD uint32_t tb_byte(const JobView& V, uint32_t c, uint32_t i, uint32_t j) {
     const uint32_t raw = V.tb[(size_t)(j - 1) * V.Rtot + V.cd[c].roff + tb_row_offset(V.tb_keyfmt, V.cd[c], i)];
-    if (!V.tb_keyfmt) return raw;
+    if (V.tb_keyfmt == 0 || V.tb_keyfmt == 3) return raw;
     return key_code_to_generic(raw, i == 1 && (V.jt_idx[(size_t)c * (V.n + 1) + j] & JT_CIRC_BIT) != 0);
 }
 
