@@ -128,6 +128,16 @@ int stitch_shard_range(const uint8_t* bases, const uint64_t* offsets, uint32_t n
 long stitch_split_at_y(const stitch_chain* in, const stitch_op* in_ops, int32_t mode, uint32_t y_pivot,
                        stitch_chain* out, stitch_op* out_ops, uint32_t cap);
 
+/* Test hook (host only, no device needed): SamRecordFormatter::format (mod.rs:622-973, with SubAlignmentBuilder::build,
+ * sub_alignment.rs:36-241) on CALLER-SUPPLIED chains, so that hand-traced known answers for the formatter's quirks
+ * (tests/golden/sam_known_answers.json) can be checked against the library's host code without an alignment run.  Targets are
+ * given by name and length (the formatter reads nothing else of them); chain k's operations are ops[ops_begin .. ops_begin +
+ * ops_len).  Returns like stitch_format_sam. */
+long stitch_format_sam_chains(const stitch_opts*, const char* const* target_names, const uint32_t* target_lens, uint32_t n_targets,
+                             const char* head, const uint8_t* bases, const uint8_t* quals, size_t n,
+                             const stitch_chain* chains, uint32_t n_chains, const stitch_op* ops,
+                             int has_prealign, int32_t prealign, char* buf, size_t cap);
+
 const char* stitch_last_error(void);
 const char* stitch_version(void);
 

@@ -240,6 +240,11 @@ class Aligners:
     def cells(self):
         return int(lib().orc_al_cells(self.h))
 
+    def set_chains(self, chains):
+        """Test hook: replace the chains format_sam works on with caller-supplied Alignments."""
+        for k, a in enumerate(chains):
+            lib().orc_al_set_chain(self.h, C.c_size_t(k), a.to_wire())
+
     def prealign_score(self):
         """The pre-alignment score of the last align() (None without --pre-align or when nothing passed)."""
         v = C.c_int32(0)

@@ -177,6 +177,14 @@ long orc_al_chain(void* hh, size_t k, int64_t* out, size_t cap) {
     auto* h = (OrcAligners*)hh;
     return k < h->chains.size() ? (long)put_alignment(h->chains[k], out, cap) : -1;
 }
+// Test hook: replace the chains of the last orc_al_align with caller-supplied ones (k == 0 clears first), so that
+// orc_al_format_sam can be checked against hand-traced known answers (tests/golden/sam_known_answers.json).
+int orc_al_set_chain(void* hh, size_t k, const int64_t* in) {
+    auto* h = (OrcAligners*)hh;
+    if (k == 0) h->chains.clear();
+    h->chains.push_back(get_alignment(in));
+    return (int)h->chains.size();
+}
 uint64_t orc_al_cells(void* hh) { return ((OrcAligners*)hh)->al.multi_contig.cells_filled; }
 // SAM text of the chains of the last orc_al_align call; records joined with '\n'.  has_prealign: xs source.
 long orc_al_format_sam(void* hh, const char* head, const uint8_t* bases, size_t n, const uint8_t* quals,

@@ -60,7 +60,7 @@ class _Timing(C.Structure):  # == stitch_timing
 
 EXPORTS = ("stitch_opts_default", "stitch_index_build", "stitch_index_serialize", "stitch_index_deserialize",
            "stitch_index_n_contigs", "stitch_index_destroy", "stitch_ctx_create", "stitch_ctx_destroy", "stitch_align_batch",
-           "stitch_format_sam", "stitch_last_timing", "stitch_prealign_band", "stitch_split_at_y", "stitch_shard_range", "stitch_last_error", "stitch_version")
+           "stitch_format_sam", "stitch_format_sam_chains", "stitch_last_timing", "stitch_prealign_band", "stitch_split_at_y", "stitch_shard_range", "stitch_last_error", "stitch_version")
 
 _lib = None
 
@@ -76,6 +76,7 @@ def lib():
         L.stitch_last_error.restype = C.c_char_p
         L.stitch_version.restype = C.c_char_p
         L.stitch_format_sam.restype = C.c_long
+        L.stitch_format_sam_chains.restype = C.c_long
         L.stitch_split_at_y.restype = C.c_long
         L.stitch_index_n_contigs.restype = C.c_uint32
         _lib = L
@@ -170,6 +171,39 @@ def split_at_y(aln, mode, y_pivot):
         setattr(r, f, int(getattr(out, f)))
     r.operations = [(int(o.kind), int(o.contig), int(o.arg)) if o.kind == 6 else (int(o.kind), int(o.arg) if o.kind in (4, 5, 7) else 0, 0) for o in out_ops[:n]]
     return r
+
+
+def format_sam_chains(builder, targets, head, bases, quals, chains, prealign=None):
+    """SamRecordFormatter::format (mod.rs:622-973) on caller-supplied chains, as the library's host code implements it (no device
+    needed).  `targets` = [(name, length)], `chains` = [Alignment]; returns the SAM lines."""
+    names = (C.c_char_p * len(targets))(*[n.encode() for n, _ in targets])
+    lens = (C.c_uint32 * len(targets))(*[int(l) for _, l in targets])
+    n_ops = sum(len(a.operations) for a in chains)
+    ops = (_Op * max(1, n_ops))()
+    chs = (_Chain * max(1, len(chains)))()
+    at = 0
+    for k, aln in enumerate(chains):
+        for f in Alignment.__slots__[:-1]:
+            setattr(chs[k], f, getattr(aln, f))
+        chs[k].ops_begin, chs[k].ops_len = at, len(aln.operations)
+        for kind, a, b in aln.operations:
+            ops[at].kind = kind
+            ops[at].contig = a if kind == 6 else 0
+            ops[at].arg = b if kind == 6 else a
+            at += 1
+    b = bases.encode() if isinstance(bases, str) else bytes(bases)
+    q = None if quals is None else (quals.encode() if isinstance(quals, str) else bytes(quals))
+    opts = builder.build_options()
+    cap = 1 << 16
+    while True:
+        buf = C.create_string_buffer(cap)
+        n = lib().stitch_format_sam_chains(C.byref(opts), names, lens, C.c_uint32(len(targets)), head.encode(), b, q, C.c_size_t(len(b)), chs,
+                                           C.c_uint32(len(chains)), ops, int(prealign is not None), C.c_int32(prealign or 0), buf, C.c_size_t(cap))
+        if n < 0:
+            raise StitchError(lib().stitch_last_error().decode())
+        if n < cap:
+            return buf.value.decode().split("\n")
+        cap = n + 1
 
 
 class Builder:

@@ -1306,6 +1306,27 @@ long stitch_format_sam(stitch_ctx* c, uint32_t read_idx, const char* head, const
     return (long)all.size();
 }
 
+long stitch_format_sam_chains(const stitch_opts* o, const char* const* target_names, const uint32_t* target_lens, uint32_t n_targets, const char* head,
+                             const uint8_t* bases, const uint8_t* quals, size_t n, const stitch_chain* chains, uint32_t n_chains, const stitch_op* ops,
+                             int has_prealign, int32_t prealign, char* buf, size_t cap) {
+    if (!o || !target_names || !target_lens || !head || !bases || (!chains && n_chains)) return fail(STITCH_EINVAL, "null argument");
+    std::vector<TargetInfo> targets;
+    for (uint32_t t = 0; t < n_targets; ++t) targets.push_back(TargetInfo{target_names[t], target_lens[t]});
+    std::vector<HAln> al(n_chains);
+    for (uint32_t k = 0; k < n_chains; ++k) {
+        const stitch_chain& ch = chains[k]; HAln& a = al[k];
+        a.score = ch.score; a.xstart = ch.xstart; a.xend = ch.xend; a.ystart = ch.ystart; a.yend = ch.yend; a.xlen = ch.xlen; a.ylen = ch.ylen;
+        a.start_contig_idx = ch.start_contig_idx; a.end_contig_idx = ch.end_contig_idx; a.length = ch.length;
+        if (ch.ops_len) a.ops.assign(ops + ch.ops_begin, ops + ch.ops_begin + ch.ops_len);
+    }
+    std::vector<std::string> recs; std::string err;
+    if (!format_sam_records(*o, targets, head, bases, quals, n, al, has_prealign != 0, prealign, recs, err)) return fail(STITCH_EINVAL, err);
+    std::string all;
+    for (size_t k = 0; k < recs.size(); ++k) { if (k) all += "\n"; all += recs[k]; }
+    if (buf && all.size() < cap) memcpy(buf, all.c_str(), all.size() + 1);
+    return (long)all.size();
+}
+
 int stitch_prealign_band(const uint8_t* read, uint32_t read_len, const uint8_t* target, uint32_t target_len, uint32_t k, uint32_t w,
                          int32_t match, int32_t gap_open, int32_t gap_extend, uint16_t* lo, uint16_t* hi) {
     if (!read || !target || !lo || !hi) return fail(STITCH_EINVAL, "null argument");

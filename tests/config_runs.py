@@ -1,8 +1,10 @@
 """Measurement tool (not collected by pytest): the other BASELINE.json configurations, at their shapes, through the C ABI.
 
-    python tests/config_runs.py --config cfg1|cfg3|cfg5 [--reads N] [--out gpurun_out/x.json]
+    python tests/config_runs.py --config cfg1|cfg2|cfg3|cfg5 [--mode M] [--reads N] [--out gpurun_out/x.json]
 
 cfg1  1000 x 150 bp vs one 5 kb contig, local               (every read also checked against the oracle)
+cfg2  10 kb reads vs 50 x 5 kb, single strand, in the clipping mode --mode names (local: what bench.py measures; query-local,
+      target-local, global: the 32-bit register-resident kernel, fill_regs32.hip)
 cfg3  10 kb reads vs 50 x 5 kb, --double-strand --pre-align (k=12, w=50, s=100, subset)
 cfg5  20 kb PacBio-like reads vs 200 x 5 kb circular, --circular --suboptimal
 
@@ -35,7 +37,8 @@ def rescore(ops):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", required=True, choices=["cfg1", "cfg3", "cfg5"])
+    ap.add_argument("--config", required=True, choices=["cfg1", "cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--mode", default="local", choices=["local", "query-local", "target-local", "global"])
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--out", default="")
@@ -49,6 +52,12 @@ def main():
         reads = synth.make_reads(db, n_reads, 150, 43, max_segments=1)
         opts = {}
         batch = args.batch or 1000
+    elif args.config == "cfg2":
+        db = synth.make_db(50, 5000, 1001)
+        n_reads = args.reads or 76
+        reads = synth.make_reads(db, n_reads, 10000, 44)
+        opts = dict(mode=args.mode)
+        batch = args.batch or (78 if args.mode == "local" else 38)        # two launches: 39 reads fill fill_regs' 512 workgroup slots, 19 fill_regs32's 256
     elif args.config == "cfg3":
         db = synth.make_db(50, 5000, 1001)
         n_reads = args.reads or 512
@@ -88,7 +97,7 @@ def main():
         mapped += int((rr["n_chains"] > 0).sum())
         t_check += time.perf_counter() - tc
     dt = time.perf_counter() - t0 - t_check
-    out = {"config": args.config, "reads": len(reads), "batch": batch, "seconds": dt, "reads_per_sec": len(reads) / dt,
+    out = {"config": args.config, "mode": args.mode, "fill_kind": al.timing().get("fill_kind"), "reads": len(reads), "batch": batch, "seconds": dt, "reads_per_sec": len(reads) / dt,
            "gcells_per_sec": tot["cells"] / dt / 1e9, "chains": n_chains, "chains_whose_ops_do_not_rescore": None if args.config == "cfg5" else n_bad,
            "reads_with_chains": mapped, **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in tot.items()}}
 
