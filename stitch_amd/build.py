@@ -21,7 +21,8 @@ def needs_build():
 # per-file compiler flags.  fill_regs.hip: its sweeps are long straight-line blocks of compare -> select pairs, and gfx950 wants two
 # wait states between a vector compare's scalar result and the vector instruction that reads it; the default scheduler leaves ~300
 # s_nop in the column loop, the ILP scheduler ~90 (each an issue slot of a wave that is short of them: -2 % launch time, measured).
-FILE_FLAGS = {"fill_regs.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
+FILE_FLAGS = {"fill_regs.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+              "fill_regs32.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}      # (+3 % on the cfg2 shape in global mode, measured)
 
 
 def build(force=False, verbose=False):

@@ -8,7 +8,7 @@
 // (walk_core.h tb_row_offset) — with the generic recurrence (dp_core.h row_phase_a / row_phase_c, single_contig_aligner.rs:
 // 292-451) on THREE registers per row: S (int32), D (int32) and the two 16-bit alignment lengths packed in one register.
 // 80 rows x 3 = 240 registers do not fit the 256 a wave has at two waves per SIMD: the kernel runs ONE wave per SIMD (a 256-thread
-// workgroup per CU, waves_per_eu = 1) with the packed lengths and the y-suffix maxima in the wave's accumulation registers
+// workgroup per CU, waves_per_eu = 1) with D (read and written once per column) and the y-suffix maxima in the wave's accumulation registers
 // (gfx950: 256 VGPRs + 256 AGPRs per wave at this occupancy; v_accvgpr_read / _write move a value across: one instruction).
 //
 // What the clipping modes change (aligners/constants.rs:96-136, aligners/mod.rs:123-131): each of the four clip penalties is 0
@@ -64,6 +64,17 @@ __device__ __forceinline__ uint32_t sel_lanes(const unsigned long long lanes, co
     uint32_t r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(lanes)); return r;
 }
 
+// In-kernel stamps (diagnostic build only, -DSTITCH_PROFILE): per-wave cycle sums of the column loop's sections (fill_regs.hip's scheme)
+#ifdef STITCH_PROFILE
+#define RPROF_DECL uint32_t pf_t = (uint32_t)__builtin_readcyclecounter(), pf_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RPROF(k) { const uint32_t pf_n = (uint32_t)__builtin_readcyclecounter(); pf_sum[k] += pf_n - pf_t; pf_t = pf_n; }
+#else
+#define RPROF_DECL
+#define RPROF(k)
+#endif
+
+__device__ __forceinline__ uint32_t byte_set_mv(const uint32_t w, const int k, const uint32_t mv) { return (w & ~(7u << (8 * k))) | (mv << (8 * k)); }      // the move code of byte k
+
 // wave-uniform values of one contig's column and the lane's rolling values of pass 1
 struct Col32 {
     int32_t match, mismatch, ge, goe, jscore; uint32_t jlen;
@@ -74,14 +85,17 @@ struct Col32 {
 };
 
 // ---- pass 1, one row: everything of the cell that needs column j-1 only (dp_core.h row_phase_a without the prefix clips), in
-// place; best{diagonal, deletion} is parked in LDS for the merges
+// place; best{diagonal, deletion} is parked in LDS for the merges.
+// (Measured dead end, round 3: splitting this sweep into a part that runs BEFORE the team's granules are polled (deletion, diagonal)
+// and the jump on top of it afterwards, to overlap the exchange with arithmetic — 15 more instructions per row, no gain: in-kernel
+// stamps put the poll at 4 % of the column; a lone wave per SIMD loses its time between dependent instructions, not in the exchange.)
 template <int IDX, bool CIRC>
-__device__ __forceinline__ void row32_pass1(int32_t& Sreg, int32_t& Dreg, uint32_t& La, uint32_t& tbw, Col32& c, const uint32_t xcur, uint32_t& xnext,
+__device__ __forceinline__ void row32_pass1(int32_t& Sreg, uint32_t& Da, uint32_t& Lreg, uint32_t& tbw, Col32& c, const uint32_t xcur, uint32_t& xnext,
                                             const uint32_t* xw_lane, int32_t* bs_lane) {
     constexpr int k = IDX & 3;
     const int32_t a = c.a, DG = c.DG; const uint32_t DGl = c.DGl;
-    const int32_t Sold = Sreg, Dold = Dreg;
-    const uint32_t L1 = aget(La) + 0x00010001u;               // (S.len + 1) | (D.len + 1) << 16
+    const int32_t Sold = Sreg, Dold = (int32_t)aget(Da);
+    const uint32_t L1 = Lreg + 0x00010001u;                   // (S.len + 1) | (D.len + 1) << 16
     if (IDX > 0) {
         if (k == 3 && IDX >= 7) xnext = xw_lane[((IDX >= 7 ? IDX - 7 : 0) >> 2) * 64];
         const uint32_t xbn = ((k == 0 ? xnext : xcur) >> (8 * (k == 0 ? 3 : k - 1))) & 0xFFu;
@@ -96,13 +110,14 @@ __device__ __forceinline__ void row32_pass1(int32_t& Sreg, int32_t& Dreg, uint32
     const int32_t bs2 = c1 ? BD : DG; const uint32_t bs2l = c1 ? BDl : DGl;
     int32_t J = c.jscore + a; uint32_t Jl = c.jlen, jmv = MV_JUMP;
     if (CIRC && k == 3) { J += c.jfix; Jl = c.jl1; jmv = c.jmv1; c.jfix = 0; c.jl1 = c.jlen; c.jmv1 = MV_JUMP; }
-    const bool c3 = J > bs2 || (J == bs2 && !c1 && Jl > DGl); // (:373-382)
-    const int32_t T = c3 ? J : bs2; const uint32_t Tl = c3 ? Jl : bs2l;
+    // (:373-382; bit operations, not && / ||: the compiler turns the short-circuit form into a divergent branch per row)
+    const bool c3 = (J > bs2) | ((J == bs2) & !c1 & (Jl > DGl));
+    const int32_t T = J > bs2 ? J : bs2; const uint32_t Tl = c3 ? Jl : bs2l;      // (where c3 differs from J > bs2 the scores are equal)
     const uint32_t code = (c3 ? jmv : c1 ? (uint32_t)MV_DEL : (uint32_t)MV_DIAG) | (dext ? (uint32_t)TBB_DEXT : 0u);
     tbw = k == 3 ? code : ((tbw << 8) | code);
     bs_lane[IDX * 64] = bs2;
     if (IDX < 8) { if (c.padreg == (uint32_t)IDX) c.dgm = DG; }
-    Sreg = T; Dreg = BD; aput(La, Tl | (BDl << 16));
+    Sreg = T; aput(Da, (uint32_t)BD); Lreg = Tl | (BDl << 16);
 }
 
 // what a merge or a prefix clip needs of the column and of the lane (positions are 1-based rows of the contig)
@@ -131,16 +146,16 @@ __device__ __forceinline__ void clips32(const Ctx32& X, int32_t& bs, uint32_t& l
 }
 // rows of a group after pass 1, in the columns where a prefix clip can win
 template <int IDX>
-__device__ __forceinline__ void clip32_row(int32_t& Sreg, uint32_t& La, uint32_t& tbw, const Ctx32& X) {
+__device__ __forceinline__ void clip32_row(int32_t& Sreg, uint32_t& Lreg, uint32_t& tbw, const Ctx32& X) {
     constexpr int k = IDX & 3;
-    int32_t bs = Sreg; const uint32_t L = aget(La); uint32_t ln = L & 0xFFFFu, mv = 0xFFu;
+    int32_t bs = Sreg; const uint32_t L = Lreg; uint32_t ln = L & 0xFFFFu, mv = 0xFFu;
     clips32<IDX>(X, bs, ln, mv);
-    if (mv != 0xFFu) { Sreg = bs; aput(La, (L & 0xFFFF0000u) | ln); tbw = byte_set(tbw, k, mv); }
+    if (mv != 0xFFu) { Sreg = bs; Lreg = (L & 0xFFFF0000u) | ln; tbw = byte_set(tbw, k, mv); }
 }
 // ---- phase C of dp_core.h for the lanes of `m`: the insertion (bi, il) at its place in the priority order, then the jump and
 // the prefix clips again; a cell the insertion does not beat best{diagonal, deletion} in stays as it is
 template <int IDX>
-__device__ __forceinline__ void merge32_row(int32_t& Sreg, uint32_t& La, uint32_t& tbw, const unsigned long long m, const int32_t bi, const uint32_t il,
+__device__ __forceinline__ void merge32_row(int32_t& Sreg, uint32_t& Lreg, uint32_t& tbw, const unsigned long long m, const int32_t bi, const uint32_t il,
                                             const Ctx32& X, const int32_t* bs_lane) {
     constexpr int k = IDX & 3;
     if (sel_lanes(m, 1u) == 0u) return;
@@ -153,19 +168,19 @@ __device__ __forceinline__ void merge32_row(int32_t& Sreg, uint32_t& La, uint32_
     const int32_t J = (pos == 1 ? X.j1score : X.jscore) + a;
     if (J > bs) { bs = J; ln = pos == 1 ? X.j1len : X.jlen; mv = pos == 1 ? X.j1mv : (uint32_t)MV_JUMP; }      // (the == rule needs bs == diagonal: impossible here)
     clips32<IDX>(X, bs, ln, mv);
-    Sreg = bs; aput(La, (aget(La) & 0xFFFF0000u) | (ln & 0xFFFFu)); tbw = byte_set(tbw, k, mv);
+    Sreg = bs; Lreg = (Lreg & 0xFFFF0000u) | (ln & 0xFFFFu); tbw = byte_set(tbw, k, mv);
 }
 
 // ---- pass 1b: the chain of the lane's own openers (score, length, "arrived by an extension")
 struct Chain32 { int32_t ge, goe; int32_t Is; uint32_t Il; uint32_t extn; };
 template <int IDX>
-__device__ __forceinline__ void chain32_row(const int32_t Sreg, const uint32_t& La, uint32_t& eb, Chain32& c, int32_t& Is_at, uint32_t& Il_at) {
+__device__ __forceinline__ void chain32_row(const int32_t Sreg, const uint32_t Lreg, uint32_t& eb, Chain32& c, int32_t& Is_at, uint32_t& Il_at) {
     constexpr int k = IDX & 3;
     Is_at = c.Is; Il_at = c.Il;
     eb |= c.extn << (8 * k);
     const int32_t ext = c.Is + c.ge, open = Sreg + c.goe;
     const bool isext = ext >= open;                            // the extension wins ties (:321)
-    const uint32_t ol = (aget(La) & 0xFFFFu) + 1u;
+    const uint32_t ol = (Lreg & 0xFFFFu) + 1u;
     c.Il = isext ? c.Il + 1u : ol;
     c.Is = isext ? ext : open;
     c.extn = isext ? (uint32_t)TBB_IEXT : 0u;
@@ -198,7 +213,13 @@ __device__ __forceinline__ void group32_records(Recs32& R, const uint32_t g4, co
     R.g1 = (g4 >> 16) > (R.bw >> 16) ? g : R.g1;
     R.bw = g4 > R.bw ? g4 : R.bw;
 }
+// (every row a lane processes outside row m's group is a real row, and a real cell's score lies in (kbase, kbase + 65536): it is at
+// least the column's jump candidate, colmax_prev + a jump score + a mismatch, and at most colmax_prev + match — regs32_plan keeps
+// the scoring within KEY_BIAS.  The clamp only serves the registers without a row, whose key nobody looks at.)
 __device__ __forceinline__ uint32_t rel_key(const int32_t S, const uint32_t L, const int32_t kbase) {
+    return __builtin_amdgcn_perm((uint32_t)(S - kbase), L, 0x05040100u);      // bytes 1..0 of (S - kbase) above bytes 1..0 of L
+}
+__device__ __forceinline__ uint32_t rel_key_clamped(const int32_t S, const uint32_t L, const int32_t kbase) {
     int32_t r = S - kbase; r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
     return ((uint32_t)r << 16) | (L & 0xFFFFu);
 }
@@ -260,8 +281,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool mine = lane == mlane;
 
     // ---- column 0 (init_matrices :97-186) -----------------------------------------------------------------------------------------
-    int32_t S[RMAX], D[RMAX];
-    uint32_t LA[RMAX], SNA[RMAX];                                   // accumulation registers: packed lengths; y-suffix maxima Sn
+    int32_t S[RMAX]; uint32_t L[RMAX];                              // vector registers: S, and S.len | D.len << 16
+    uint32_t DA[RMAX], SNA[RMAX];                                   // accumulation registers: D (read and written once per column), the y-suffix maxima Sn
     {
         uint32_t* const xw0 = (uint32_t*)(s_wave + LDS_XW) + lane;
         for_groups_down<NG - 1>([&](auto gi) __attribute__((always_inline)) {
@@ -281,7 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     V.SmoveF[roff + row] = TB_NONE; V.ImoveF[roff + row] = TB_NONE;
                     b = V.xseq[cd.seqoff + row];
                 }
-                S[4 * g + k] = s; D[4 * g + k] = MIN_SCORE; aput(LA[4 * g + k], l & 0xFFFFu); aput(SNA[4 * g + k], (uint32_t)sn);
+                S[4 * g + k] = s; aput(DA[4 * g + k], (uint32_t)MIN_SCORE); L[4 * g + k] = l & 0xFFFFu; aput(SNA[4 * g + k], (uint32_t)sn);
                 w |= b << (8 * k);
             }
             xw0[g * 64] = w;
@@ -331,8 +352,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     uint32_t ychunk = 0;
+    RPROF_DECL
     for (uint32_t j = 1; j <= n; ++j) {
         const bool lastcol = j == n;
+        RPROF(7)
+        if (((j - 1) & 63u) == 0) ychunk = (j - 1 + lane < n) ? (uint32_t)yseq[j - 1 + lane] : 0u;
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)ychunk, (int)((j - 1) & 63u)) & 0xFFu;
+        const Row0 r0 = row0_step(P, j, n, sn0, ly0);                // row 0 of this column (closed form, :188-239)
+
+        const uint32_t* const xw_lane = (const uint32_t*)(s_wave + LDS_XW) + lane;
+        int32_t* const bs_lane = (int32_t*)(s_wave + LDS_BS) + lane;
+        uint32_t tbv[NG];
+        // (the group guards are compared where they are used: kept as twenty hoisted masks per sweep they take scalar registers by the
+        // dozen, and what depends only on the lane would be pinned in vector registers over the whole read)
+        uint32_t gtop_x = gtop; asm volatile("" : "+s"(gtop_x));
+        bool has0_x; { uint32_t h = has0 ? 1u : 0u; asm volatile("" : "+v"(h)); has0_x = h != 0u; }
+#define GUARD32(g) ((g) == 0 ? has0_x : ({ asm volatile("" : "+s"(gtop_x)); (uint32_t)(g) < gtop_x; }))
+        RPROF(0)
         // ---- poll the team's granules of column j-1 (two tagged 8-byte halves per contig: {column, len, from} and {column, score}) ----
         if (j > 1) {
             const uint32_t want = j - 1;
@@ -362,10 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             colmax_prev = (int32_t)(wave_max_u32((uint32_t)best ^ 0x80000000u) ^ 0x80000000u);
             gmax = colmax_prev > gmax ? colmax_prev : gmax;
         }
-        if (((j - 1) & 63u) == 0) ychunk = (j - 1 + lane < n) ? (uint32_t)yseq[j - 1 + lane] : 0u;
-        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)ychunk, (int)((j - 1) & 63u)) & 0xFFu;
-        const Row0 r0 = row0_step(P, j, n, sn0, ly0);                // row 0 of this column (closed form, :188-239)
-
+        RPROF(1)
         // ---- best jump out of column j-1 for this contig (multi_contig_aligner.rs:292-331) --------------------------------------------
         auto sc_of = [&](uint32_t k) -> int32_t { int32_t v = gsc[0];
 #pragma unroll
@@ -407,13 +440,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
         Ctx32 X;
         X.match = P.match; X.mismatch = P.mismatch; X.go = P.gap_open; X.ge = ge; X.jscore = jscore; X.jlen = jlen; X.j1score = j1score; X.j1len = j1len; X.j1mv = j1mv;
-        X.q = q; X.xf = xf; X.yf = yf; X.row0_len = r0.Slen; X.pos_reg0 = pos_reg0; X.m = m; X.col0_len = sh.Slen0 + cd.troff;
+        int32_t pos_x = pos_reg0; asm volatile("" : "+v"(pos_x));      // (opaque per column: the compiler would otherwise compute every row's position-dependent
+                                                                       // term once per read and keep 80 of them per lane — in scratch)
+        X.q = q; X.xf = xf; X.yf = yf; X.row0_len = r0.Slen; X.pos_reg0 = pos_x; X.m = m; X.col0_len = sh.Slen0 + cd.troff;
         { const int32_t go_j = P.gap_open + P.gap_extend * (int32_t)j; X.xclip_score = P.xclip_prefix + (P.yclip_prefix > go_j ? P.yclip_prefix : go_j); }      // :304-308
-        const uint32_t* const xw_lane = (const uint32_t*)(s_wave + LDS_XW) + lane;
         X.xw_lane = xw_lane;
-        int32_t* const bs_lane = (int32_t*)(s_wave + LDS_BS) + lane;
-        uint32_t tbv[NG];
 
+        RPROF(2)
         // ---- pass 1 -----------------------------------------------------------------------------------------------------------------
         Col32 cx;
         cx.match = P.match; cx.mismatch = P.mismatch; cx.ge = ge; cx.goe = goe; cx.jscore = jscore; cx.jlen = jlen; cx.q = q;
@@ -422,7 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         uint32_t xwA = xw_lane[(gtop - 1u) * 64], xwB = xwA;
         cx.a = (xwA >> 24) == q ? cx.match : cx.mismatch;
         {   // the row above a lane's first row: the previous lane's last row (its register rsh); row 0 of column j-1 for lane 0
-            const int32_t s_last = rsh ? S[4] : S[0]; const uint32_t l_last = (rsh ? aget(LA[4]) : aget(LA[0])) & 0xFFFFu;
+            const int32_t s_last = rsh ? S[4] : S[0]; const uint32_t l_last = (rsh ? L[4] : L[0]) & 0xFFFFu;
             cx.DG = from_prev_lane(s_last, r0prev.S) + cx.a; cx.DGl = (uint32_t)from_prev_lane((int)l_last, (int)r0prev.Slen) + 1u;
         }
         // the prefix clips can only win below this bound of every cell's jump candidate
@@ -430,37 +463,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool may_clip = (xf && jw_floor < X.xclip_score) || (yf && jw_floor < goe);
         for_groups_down<NG - 1>([&](auto gi) __attribute__((always_inline)) {
             constexpr int g = decltype(gi)::v;
-            if (g == 0 ? has0 : (uint32_t)g < gtop) {
+            if (GUARD32(g)) {
                 uint32_t tbw = 0;
                 uint32_t& xc = (g & 1) ? xwB : xwA; uint32_t& xn = (g & 1) ? xwA : xwB;
-                row32_pass1<4 * g + 3, CIRC>(S[4 * g + 3], D[4 * g + 3], LA[4 * g + 3], tbw, cx, xc, xn, xw_lane, bs_lane);
-                row32_pass1<4 * g + 2, CIRC>(S[4 * g + 2], D[4 * g + 2], LA[4 * g + 2], tbw, cx, xc, xn, xw_lane, bs_lane);
-                row32_pass1<4 * g + 1, CIRC>(S[4 * g + 1], D[4 * g + 1], LA[4 * g + 1], tbw, cx, xc, xn, xw_lane, bs_lane);
-                row32_pass1<4 * g, CIRC>(S[4 * g], D[4 * g], LA[4 * g], tbw, cx, xc, xn, xw_lane, bs_lane);
+                row32_pass1<4 * g + 3, CIRC>(S[4 * g + 3], DA[4 * g + 3], L[4 * g + 3], tbw, cx, xc, xn, xw_lane, bs_lane);
+                row32_pass1<4 * g + 2, CIRC>(S[4 * g + 2], DA[4 * g + 2], L[4 * g + 2], tbw, cx, xc, xn, xw_lane, bs_lane);
+                row32_pass1<4 * g + 1, CIRC>(S[4 * g + 1], DA[4 * g + 1], L[4 * g + 1], tbw, cx, xc, xn, xw_lane, bs_lane);
+                row32_pass1<4 * g, CIRC>(S[4 * g], DA[4 * g], L[4 * g], tbw, cx, xc, xn, xw_lane, bs_lane);
                 if (__builtin_expect(may_clip, 0)) {
-                    clip32_row<4 * g + 3>(S[4 * g + 3], LA[4 * g + 3], tbw, X); clip32_row<4 * g + 2>(S[4 * g + 2], LA[4 * g + 2], tbw, X);
-                    clip32_row<4 * g + 1>(S[4 * g + 1], LA[4 * g + 1], tbw, X); clip32_row<4 * g>(S[4 * g], LA[4 * g], tbw, X);
+                    clip32_row<4 * g + 3>(S[4 * g + 3], L[4 * g + 3], tbw, X); clip32_row<4 * g + 2>(S[4 * g + 2], L[4 * g + 2], tbw, X);
+                    clip32_row<4 * g + 1>(S[4 * g + 1], L[4 * g + 1], tbw, X); clip32_row<4 * g>(S[4 * g], L[4 * g], tbw, X);
                 }
                 tbv[g] = tbw;
             }
         });
+        RPROF(3)
         // ---- pass 1b: the chain of the lane's own openers ---------------------------------------------------------------------------------
         Chain32 cl; cl.ge = ge; cl.goe = goe; cl.Is = CHAIN_NONE32; cl.Il = 0u; cl.extn = 0u;
         for_groups_down<NG - 1>([&](auto gi) __attribute__((always_inline)) {
             constexpr int g = decltype(gi)::v;
-            if (g == 0 ? has0 : (uint32_t)g < gtop) {
+            if (GUARD32(g)) {
                 uint32_t eb = 0u; int32_t i3, i2, i1, i0; uint32_t n3, n2, n1, n0;
-                chain32_row<4 * g + 3>(S[4 * g + 3], LA[4 * g + 3], eb, cl, i3, n3); chain32_row<4 * g + 2>(S[4 * g + 2], LA[4 * g + 2], eb, cl, i2, n2);
-                chain32_row<4 * g + 1>(S[4 * g + 1], LA[4 * g + 1], eb, cl, i1, n1); chain32_row<4 * g>(S[4 * g], LA[4 * g], eb, cl, i0, n0);
+                chain32_row<4 * g + 3>(S[4 * g + 3], L[4 * g + 3], eb, cl, i3, n3); chain32_row<4 * g + 2>(S[4 * g + 2], L[4 * g + 2], eb, cl, i2, n2);
+                chain32_row<4 * g + 1>(S[4 * g + 1], L[4 * g + 1], eb, cl, i1, n1); chain32_row<4 * g>(S[4 * g], L[4 * g], eb, cl, i0, n0);
                 uint32_t tbw = tbv[g] | eb;
                 const unsigned long long m3 = __ballot(i3 >= S[4 * g + 3]), m2 = __ballot(i2 >= S[4 * g + 2]), m1 = __ballot(i1 >= S[4 * g + 1]), m0 = __ballot(i0 >= S[4 * g]);
                 if (__builtin_expect((m3 | m2 | m1 | m0) != 0ull, 0)) {
-                    merge32_row<4 * g + 3>(S[4 * g + 3], LA[4 * g + 3], tbw, m3, i3, n3, X, bs_lane); merge32_row<4 * g + 2>(S[4 * g + 2], LA[4 * g + 2], tbw, m2, i2, n2, X, bs_lane);
-                    merge32_row<4 * g + 1>(S[4 * g + 1], LA[4 * g + 1], tbw, m1, i1, n1, X, bs_lane); merge32_row<4 * g>(S[4 * g], LA[4 * g], tbw, m0, i0, n0, X, bs_lane);
+                    merge32_row<4 * g + 3>(S[4 * g + 3], L[4 * g + 3], tbw, m3, i3, n3, X, bs_lane); merge32_row<4 * g + 2>(S[4 * g + 2], L[4 * g + 2], tbw, m2, i2, n2, X, bs_lane);
+                    merge32_row<4 * g + 1>(S[4 * g + 1], L[4 * g + 1], tbw, m1, i1, n1, X, bs_lane); merge32_row<4 * g>(S[4 * g], L[4 * g], tbw, m0, i0, n0, X, bs_lane);
                 }
                 tbv[g] = tbw;
             }
         });
+        RPROF(4)
         int32_t Iin_s; uint32_t Iin_l, extin;
         chain_across_lanes(cl.Is, cl.Il, cl.extn != 0u, r0, Iin_s, Iin_l, extin);
 
@@ -475,27 +510,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned long long have0 = __ballot(has0);
         for_groups_down<NG - 1>([&](auto gi) __attribute__((always_inline)) {
             constexpr int g = decltype(gi)::v;
-            if ((uint32_t)g < gtop) {
+            if (({ asm volatile("" : "+s"(gtop_x)); (uint32_t)g < gtop_x; })) {
                 if (g == 0) ca.alive &= have0;
                 uint32_t tbw = tbv[g];
-                if (ca.alive != 0ull) group32_alive<g>(S[4 * g + 3], S[4 * g + 2], S[4 * g + 1], S[4 * g], LA[4 * g + 3], LA[4 * g + 2], LA[4 * g + 1], LA[4 * g], tbw, ca, X, bs_lane);
-                if (g == 0 ? has0 : true) {
+                if (ca.alive != 0ull) group32_alive<g>(S[4 * g + 3], S[4 * g + 2], S[4 * g + 1], S[4 * g], L[4 * g + 3], L[4 * g + 2], L[4 * g + 1], L[4 * g], tbw, ca, X, bs_lane);
+                if (g == 0 ? has0_x : true) {
                     const bool rmg = g < 2 && (uint32_t)g == gm && mine;      // the group of row m, in its lane: registers <= pad hold no row below m
-                    const uint32_t k3 = (rmg && 3u <= pad) ? 0u : rel_key(S[4 * g + 3], aget(LA[4 * g + 3]), kbase), k2 = (rmg && 2u <= pad) ? 0u : rel_key(S[4 * g + 2], aget(LA[4 * g + 2]), kbase);
-                    const uint32_t k1 = (rmg && 1u <= pad) ? 0u : rel_key(S[4 * g + 1], aget(LA[4 * g + 1]), kbase), k0 = rmg ? 0u : rel_key(S[4 * g], aget(LA[4 * g]), kbase);
+                    const uint32_t k3 = (rmg && 3u <= pad) ? 0u : rel_key(S[4 * g + 3], L[4 * g + 3], kbase), k2 = (rmg && 2u <= pad) ? 0u : rel_key(S[4 * g + 2], L[4 * g + 2], kbase);
+                    const uint32_t k1 = (rmg && 1u <= pad) ? 0u : rel_key(S[4 * g + 1], L[4 * g + 1], kbase), k0 = rmg ? 0u : rel_key(S[4 * g], L[4 * g], kbase);
                     const uint32_t g4 = (k3 > k2 ? k3 : k2) > (k1 > k0 ? k1 : k0) ? (k3 > k2 ? k3 : k2) : (k1 > k0 ? k1 : k0);
                     group32_records(R, g4, (uint32_t)g);
                     if (yf) {
                         // may a cell of this group still matter as a y-suffix clip?  (header: local / query-local)
                         const int32_t gs = (int32_t)(g4 >> 16) + kbase;      // largest score of the group's rows below m (clamped keys only under-estimate a cell that is out of range)
-                        const int32_t via_ins = P.gap_open + ge * ((int32_t)m - (pos_reg0 - 4 * g));
+                        const int32_t via_ins = P.gap_open + ge * ((int32_t)m - (pos_x - 4 * g));
                         const int32_t bound = local_mode ? gs : gs + (P.jump_same > via_ins ? P.jump_same : via_ins);
                         const bool cand = g4 != 0u && (y_all || (local_mode ? bound >= ybase : bound > ybase));
                         if (__builtin_expect(__any(cand), 0)) {
 #pragma unroll
                             for (int k = 3; k >= 0; --k) {
                                 const bool below_m = !(rmg && (uint32_t)k <= pad);
-                                const int32_t v = S[4 * g + k]; const uint32_t ln = aget(LA[4 * g + k]) & 0xFFFFu; const int32_t snv = (int32_t)aget(SNA[4 * g + k]);
+                                const int32_t v = S[4 * g + k]; const uint32_t ln = L[4 * g + k] & 0xFFFFu; const int32_t snv = (int32_t)aget(SNA[4 * g + k]);
                                 if (cand && below_m && (v > snv || (v == snv && ln > 0u))) {      // (:431-447; cell(i, n).S.len is still 0 for i < m)
                                     aput(SNA[4 * g + k], (uint32_t)v);
                                     u32x2 rec; rec.x = ln; rec.y = ycol;
@@ -510,6 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         });
 
+        RPROF(5)
         // ---- the contig's epilogue: wave reductions over rows < m, row m, the column arg-max granule ------------------------------------------
         {
             const uint32_t xw = wave_max_u32(R.bw);
@@ -520,11 +556,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     constexpr int g = decltype(gi)::v;
                     if (Gq == (uint32_t)g) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { ws[k] = __builtin_amdgcn_readlane(S[4 * g + k], Lq); wl[k] = (uint32_t)__builtin_amdgcn_readlane((int)aget(LA[4 * g + k]), Lq) & 0xFFFFu; }
+                        for (int k = 0; k < 4; ++k) { ws[k] = __builtin_amdgcn_readlane(S[4 * g + k], Lq); wl[k] = (uint32_t)__builtin_amdgcn_readlane((int)L[4 * g + k], Lq) & 0xFFFFu; }
                     }
                 });
 #pragma unroll
-                for (int k = 0; k < 4; ++k) wk[k] = rel_key(ws[k], wl[k], kbase);
+                for (int k = 0; k < 4; ++k) wk[k] = rel_key_clamped(ws[k], wl[k], kbase);
                 if (Gq == gm && Lq == mlane) { wk[0] = 0u; if (pad >= 1u) wk[1] = 0u; if (pad >= 2u) wk[2] = 0u; if (pad >= 3u) wk[3] = 0u; }
             };
             auto row_of = [&](const uint32_t Gq, const uint32_t k, const uint32_t Lq) -> uint32_t {      // 0-based row of register 4 Gq + k of lane Lq
@@ -551,7 +587,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             // ---- row m (:350-351 seeded selection, :406-447 for i == m) -------------------------------------------------------------
             int32_t wmS = 0; uint32_t wmL = 0, wmSn = 0;
-            for_groups_down<7>([&](auto ri) __attribute__((always_inline)) { constexpr int r = decltype(ri)::v; if (padreg == (uint32_t)r) { wmS = S[r]; wmL = aget(LA[r]); wmSn = aget(SNA[r]); } });
+            for_groups_down<7>([&](auto ri) __attribute__((always_inline)) { constexpr int r = decltype(ri)::v; if (padreg == (uint32_t)r) { wmS = S[r]; wmL = L[r]; wmSn = aget(SNA[r]); } });
             const int32_t ownS = __builtin_amdgcn_readlane(wmS, mlane); const uint32_t ownSl = (uint32_t)__builtin_amdgcn_readlane((int)wmL, mlane) & 0xFFFFu;
             const int32_t ownSn = __builtin_amdgcn_readlane((int)wmSn, mlane);
             const int32_t ownDG = __builtin_amdgcn_readlane(cx.dgm, mlane);
@@ -563,13 +599,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (Sm > cb_.v) { cb_.v = Sm; cb_.row = m; cb_.len = Slm; }
             if (lane == 0) {      // the column arg-max is complete: announce it before the column's remaining work
                 u32x4 g4; g4.x = (((cb_.len + 1u) & 0xFFFFu) << 16) | (cb_.row & 0xFFFFu); g4.y = j; g4.z = (uint32_t)cb_.v; g4.w = j;
-                __builtin_amdgcn_raw_buffer_store_b128(g4, rxc, 0u, ((j & 1u) * C + kmine) * 16u, AUX_SC1 | AUX_VOLATILE);
+                __builtin_amdgcn_raw_buffer_store_b128(g4, rxc, 0u, (uint32_t)__builtin_amdgcn_readfirstlane((int)(((j & 1u) * C + kmine) * 16u)), AUX_SC1 | AUX_VOLATILE);
             }
             if (cb_.v > vrun) vrun = cb_.v;
             if (Sm > rm_run) rm_run = Sm;
             rowm_xsuf = mvm == MV_XSUF; rowm_S = Sm; rowm_len = Slm;
             if (mine) {
-                for_groups_down<7>([&](auto ri) __attribute__((always_inline)) { constexpr int r = decltype(ri)::v; if (padreg == (uint32_t)r) { S[r] = Sm; aput(LA[r], (aget(LA[r]) & 0xFFFF0000u) | (Slm & 0xFFFFu)); } });
+                for_groups_down<7>([&](auto ri) __attribute__((always_inline)) { constexpr int r = decltype(ri)::v; if (padreg == (uint32_t)r) { S[r] = Sm; L[r] = (L[r] & 0xFFFF0000u) | (Slm & 0xFFFFu); } });
                 ((gptr<uint8_t>)as_global(tb0 + (size_t)(j - 1) * Rtot))[gm * 256u + 4u * (uint32_t)lane + pad] = (uint8_t)(mvm | (ownByte & (TBB_IEXT | TBB_DEXT)));
                 if (yf) {
                     const uint32_t rl = lastcol ? (do_x_m ? ownSl : xb_.len) : 0u;
@@ -583,7 +619,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         r0prev = r0;
+        RPROF(6)
+#undef GUARD32
     }
+#ifdef STITCH_PROFILE
+    if (lane == 0) { unsigned long long* const pf = (unsigned long long*)((uint8_t*)V.err + 16); for (int k = 0; k < 8; ++k) atomicAdd(pf + k, (unsigned long long)pf_sum[k]); atomicAdd(pf + 8, 1ull); }
+#endif
     // ---- column n's arrays for the fix-up kernel (single_contig_aligner.rs:453-555): S, its lengths, the insertion chain at every row
     // (recomputed from the final cells: an opener taken from a merged cell gives the same chain), the y-suffix trackers ----------------
     {
@@ -594,7 +635,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int k = 3; k >= 0; --k) {
                     const int32_t ext = Ls + ge, open = S[4 * g + k] + goe; lext = ext >= open;
-                    Ll = lext ? Ll + 1u : (aget(LA[4 * g + k]) & 0xFFFFu) + 1u; Ls = lext ? ext : open;
+                    Ll = lext ? Ll + 1u : (L[4 * g + k] & 0xFFFFu) + 1u; Ls = lext ? ext : open;
                 }
             }
         });
@@ -608,13 +649,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const int32_t pos = pos_reg0 - (4 * g + k);
                     if (pos >= 1 && pos <= (int32_t)m) {
                         const uint32_t r = roff + (uint32_t)pos - 1u;
-                        V.S[r] = S[4 * g + k]; V.Slen[r] = aget(LA[4 * g + k]) & 0xFFFFu; V.Ival[r] = Is; V.Ilen[r] = Il;
+                        V.S[r] = S[4 * g + k]; V.Slen[r] = L[4 * g + k] & 0xFFFFu; V.Ival[r] = Is; V.Ilen[r] = Il;
                         V.Sn[r] = yf ? (int32_t)aget(SNA[4 * g + k]) : MIN_SCORE;
                         const u32x2 rec = yrec[roff + (4u * g + (uint32_t)k) * 64u + (uint32_t)lane];
                         V.SnLen[r] = yf ? rec.x : 0u; V.Ly[r] = yf ? rec.y : 0u;
                     }
                     const int32_t ext = Is + ge, open = S[4 * g + k] + goe; const bool e2 = ext >= open;
-                    Il = e2 ? Il + 1u : (aget(LA[4 * g + k]) & 0xFFFFu) + 1u; Is = e2 ? ext : open;
+                    Il = e2 ? Il + 1u : (L[4 * g + k] & 0xFFFFu) + 1u; Is = e2 ? ext : open;
                 }
             }
         });

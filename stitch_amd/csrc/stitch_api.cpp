@@ -769,9 +769,11 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         HIP_TRY(hipEventElapsedTime(&ms, c.ev[1], c.ev[2])); c.tm.walk_ms += ms;
         if (c.knobs.debug) fprintf(stderr, "[stitch] launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms, fix-up + walk %.1f ms\n", nj, G, waves, ms_fill, ms);
         if (attempt == 0) { c.tm.launches += 1; c.tm.jobs += nj; }
-        if (c.knobs.profile_dump && kind == 2u) {
-            // fill_regs.hip, -DSTITCH_PROFILE: cycle sums per section over the waves of a read
-            static const char* nm[8] = {"poll", "jump", "pass1", "pass1b", "scan", "pass2+tail", "epilogue(last: +loop end)", "loop-top"};
+        if (c.knobs.profile_dump && (kind == 2u || kind == 3u)) {
+            // fill_regs.hip / fill_regs32.hip, -DSTITCH_PROFILE: cycle sums per section over the waves of a read
+            static const char* nm2[8] = {"poll", "jump", "pass1", "pass1b", "scan", "pass2+tail", "epilogue(last: +loop end)", "loop-top"};
+            static const char* nm3[8] = {"row0+bases", "poll", "jump-select", "pass1", "pass1b", "scan+pass2+tail", "epilogue", "loop-top"};
+            const char* const* nm = kind == 2u ? nm2 : nm3;
             for (uint32_t q = 0; q < std::min(nj, 4u); ++q) {
                 unsigned long long pf[11]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[q].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
                 const double cols = (double)std::max<unsigned long long>(pf[8], 1) * (double)views[q].n;
