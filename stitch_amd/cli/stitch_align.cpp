@@ -8,21 +8,29 @@
 //
 // `--devices 0,1,...` runs one worker PROCESS per GPU (the counterpart of the reference's worker threads, align.rs:345-390): the
 // parent — which never touches a GPU — builds the reference index once and hands it to the workers as the serialized blob,
-// cuts the read stream into contiguous blocks at read-group boundaries (stitch_shard_range), starts the workers (fork + exec of
-// this program, before any GPU call) and concatenates their records in rank order behind the header: byte for byte what one
-// device writes.
+// scans the read file ONCE without keeping it (per record: byte offset, length and a 64-bit hash of the bases), cuts the stream
+// into contiguous blocks at read-group boundaries (stitch_shard_range on the hashes), starts the workers (fork + exec of this
+// program, before any GPU call; each worker seeks to the byte offset of its block) and concatenates their records in rank order
+// behind the header: byte for byte what one device writes.  With `--index-via rccl` only rank 0 reads the blob and the others
+// receive it through ONE native ncclBroadcast (RCCL over xGMI, librccl.so loaded at run time): the collective BASELINE.json's
+// north_star names; the default hands the blob over as a file.
 // The alignment itself only exists on the GPU: without a device the program stops with the library's error.
 // `--dry-run` parses the inputs and writes the header only (no device needed); `--convert-sam FILE` re-encodes a SAM
 // file as BAM (what `--output-format bam` does to the records it produces) so that the encoder can be tested alone.
+#include <dlfcn.h>
 #include <signal.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 #include <zlib.h>
+
+#include <hip/hip_runtime_api.h>
 
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -57,21 +65,24 @@ struct LineReader {       // plain or gzip (zlib reads both transparently)
 
 struct FastxReader {
     LineReader in; bool fastq; std::string pending; bool have_pending = false;
+    long long rec_off = 0, pending_off = 0;      // byte offset (in the uncompressed stream) of the header line of the record just returned
     FastxReader(const std::string& p, bool fq) : in(p), fastq(fq) {}
+    // continue at a record boundary found by an earlier scan (plain files: a seek; gzip: zlib inflates up to there, without parsing)
+    void seek(long long off) { if (off > 0 && gzseek(in.f, (z_off_t)off, SEEK_SET) < 0) die("cannot seek in " + in.path); have_pending = false; }
     bool next(Rec& r) {
         std::string l;
         if (fastq) {
-            do { if (!in.line(l)) return false; } while (l.empty());
+            do { rec_off = (long long)gztell(in.f); if (!in.line(l)) return false; } while (l.empty());
             if (l[0] != '@') die("malformed FASTQ record in " + in.path + ": " + l.substr(0, 40));
             r.head = l.substr(1); r.has_qual = true;
             if (!in.line(r.seq) || !in.line(l) || l.empty() || l[0] != '+' || !in.line(r.qual)) die("truncated FASTQ record in " + in.path);
             if (r.qual.size() != r.seq.size()) die("FASTQ record with unequal sequence and quality lengths: " + r.head);
             return true;
         }
-        if (!have_pending) { do { if (!in.line(l)) return false; } while (l.empty()); pending = l; have_pending = true; }
+        if (!have_pending) { do { pending_off = (long long)gztell(in.f); if (!in.line(l)) return false; } while (l.empty()); pending = l; have_pending = true; }
         if (pending[0] != '>') die("malformed FASTA record in " + in.path);
-        r.head = pending.substr(1); r.seq.clear(); r.qual.clear(); r.has_qual = false; have_pending = false;
-        while (in.line(l)) { if (!l.empty() && l[0] == '>') { pending = l; have_pending = true; break; } r.seq += l; }
+        r.head = pending.substr(1); r.seq.clear(); r.qual.clear(); r.has_qual = false; have_pending = false; rec_off = pending_off;
+        for (;;) { const long long at = (long long)gztell(in.f); if (!in.line(l)) break; if (!l.empty() && l[0] == '>') { pending = l; pending_off = at; have_pending = true; break; } r.seq += l; }
         return true;
     }
 };
@@ -189,6 +200,9 @@ struct Args {
     // worker mode (set by the parent of a --devices run): records [shard_lo, shard_hi) only, SAM records without header to
     // shard_out, the reference index from the serialized blob
     long shard_lo = -1, shard_hi = -1; std::string shard_out, index_blob;
+    long long shard_offset = 0;                     // byte offset of record shard_lo in the (uncompressed) read stream
+    std::string index_via = "file";                 // "file" | "rccl": how the workers of a --devices run get the index blob
+    int rccl_rank = -1, rccl_world = 0; std::string rccl_id;      // worker side of --index-via rccl
 };
 
 const char* USAGE =
@@ -214,6 +228,8 @@ const char* USAGE =
     "      --device N  --batch N   GPU ordinal (0), reads per library call (1024)\n"
     "      --devices A,B,...       one worker process per listed GPU; reads are cut into contiguous blocks at read-group\n"
     "                              boundaries, the output is the single-device output (a read FILE is needed, not stdin)\n"
+    "      --index-via file|rccl   how the workers of a --devices run get the reference index: the serialized blob as a file\n"
+    "                              (default), or one native RCCL broadcast from the first worker (one GPU per worker needed)\n"
     "      --dry-run               parse the inputs, write the header, align nothing (no GPU needed)\n";
 
 bool parse_bool(const std::string& v, bool& out) {
@@ -276,6 +292,9 @@ Args parse(int argc, char** argv) {
         else if (k == "--devices") { const std::string v = need(i); size_t p = 0; while (p <= v.size()) { size_t e = v.find(',', p); if (e == std::string::npos) e = v.size(); if (e > p) a.devices.push_back(atoi(v.substr(p, e - p).c_str())); p = e + 1; } if (a.devices.empty()) die("--devices needs a list of GPU ordinals"); }
         else if (k == "--shard") { a.shard_lo = num(i); a.shard_hi = num(i); }
         else if (k == "--shard-out") a.shard_out = need(i);
+        else if (k == "--shard-offset") a.shard_offset = atoll(need(i).c_str());
+        else if (k == "--index-via") { a.index_via = lower(need(i)); if (a.index_via != "file" && a.index_via != "rccl") die("--index-via file|rccl"); }
+        else if (k == "--rccl") { a.rccl_rank = num(i); a.rccl_world = num(i); a.rccl_id = need(i); }
         else if (k == "--index-blob") a.index_blob = need(i);
         else if (k == "--batch") a.batch = (uint32_t)std::max(1, num(i));
         else if (k == "--dry-run") a.dry_run = true;
@@ -298,6 +317,52 @@ std::string sam_header(const std::vector<std::pair<std::string, uint32_t>>& refs
     h += std::string("@PG\tID:stitch\tPN:stitch\tVN:") + stitch_version() + "\tCL:" + cl + "\n";
     return h;
 }
+
+// ---- the one collective of a multi-GPU run: the serialized reference index, broadcast from rank 0 over RCCL ------------------------
+// librccl.so is loaded at run time (the single-GPU path does not need it).  Rank 0 creates the unique id and leaves it in a file
+// the parent named; the others wait for that file.  The blob's length goes first (8 bytes), then the blob.
+struct NcclId { char internal[128]; };
+std::string rccl_broadcast_blob(int rank, int world, const std::string& id_path, const std::string& blob_in) {
+    if (!getenv("NCCL_SOCKET_IFNAME")) setenv("NCCL_SOCKET_IFNAME", "lo", 0);      // (one node: the bootstrap needs no other interface)
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL); if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) die(std::string("--index-via rccl: cannot load librccl.so: ") + dlerror());
+    typedef int (*get_id_t)(NcclId*); typedef int (*init_t)(void**, int, NcclId, int); typedef int (*bcast_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef int (*destroy_t)(void*); typedef const char* (*errstr_t)(int);
+    auto get_id = (get_id_t)dlsym(h, "ncclGetUniqueId"); auto init = (init_t)dlsym(h, "ncclCommInitRank"); auto bcast = (bcast_t)dlsym(h, "ncclBroadcast");
+    auto destroy = (destroy_t)dlsym(h, "ncclCommDestroy"); auto errstr = (errstr_t)dlsym(h, "ncclGetErrorString");
+    if (!get_id || !init || !bcast || !destroy) die("--index-via rccl: librccl.so lacks the entry points");
+    auto ok = [&](int rc, const char* what) { if (rc != 0) die(std::string("--index-via rccl: ") + what + ": " + (errstr ? errstr(rc) : "error")); };
+    NcclId id{};
+    if (rank == 0) {
+        ok(get_id(&id), "ncclGetUniqueId");
+        const std::string tmp = id_path + ".tmp"; FILE* f = fopen(tmp.c_str(), "wb"); if (!f || fwrite(&id, 1, sizeof id, f) != sizeof id) die("cannot write " + tmp); fclose(f);
+        if (rename(tmp.c_str(), id_path.c_str()) != 0) die("cannot publish " + id_path);
+    } else {
+        for (int tries = 0;; ++tries) {            // (bounded: 60 s)
+            FILE* f = fopen(id_path.c_str(), "rb");
+            if (f) { const size_t n = fread(&id, 1, sizeof id, f); fclose(f); if (n == sizeof id) break; }
+            if (tries > 6000) die("--index-via rccl: rank 0 never published the unique id");
+            usleep(10000);
+        }
+    }
+    void* comm = nullptr; ok(init(&comm, world, id, rank), "ncclCommInitRank");
+    unsigned long long len = rank == 0 ? blob_in.size() : 0; unsigned long long* d_len = nullptr; uint8_t* d_blob = nullptr;
+    if (hipMalloc((void**)&d_len, 8) != hipSuccess) die("hipMalloc failed");
+    if (hipMemcpy(d_len, &len, 8, hipMemcpyHostToDevice) != hipSuccess) die("hipMemcpy failed");
+    ok(bcast(d_len, d_len, 8, /* ncclUint8 */ 1, 0, comm, nullptr), "ncclBroadcast (length)");
+    if (hipMemcpy(&len, d_len, 8, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy failed");      // (synchronises with the null stream)
+    if (len == 0 || len > (1ull << 32)) die("--index-via rccl: implausible blob length");
+    if (hipMalloc((void**)&d_blob, len) != hipSuccess) die("hipMalloc failed");
+    if (rank == 0 && hipMemcpy(d_blob, blob_in.data(), len, hipMemcpyHostToDevice) != hipSuccess) die("hipMemcpy failed");
+    ok(bcast(d_blob, d_blob, len, 1, 0, comm, nullptr), "ncclBroadcast (blob)");
+    std::string blob(len, '\0');
+    if (hipMemcpy(&blob[0], d_blob, len, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy failed");
+    (void)hipFree(d_blob); (void)hipFree(d_len); ok(destroy(comm), "ncclCommDestroy");
+    fprintf(stderr, "stitch-align: rank %d of %d: reference index (%llu bytes) %s over RCCL\n", rank, world, len, rank == 0 ? "sent" : "received");
+    return blob;
+}
+
+uint64_t fnv1a64(const std::string& s) { uint64_t h = 1469598103934665603ull; for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; } return h; }
 
 }  // namespace
 
@@ -342,46 +407,66 @@ int main(int argc, char** argv) {
     std::vector<const char*> cn; std::vector<const uint8_t*> cs; std::vector<uint32_t> cl;
     for (size_t k = 0; k < names.size(); ++k) { cn.push_back(names[k].c_str()); cs.push_back((const uint8_t*)seqs[k].data()); cl.push_back((uint32_t)seqs[k].size()); }
     stitch_index* index = nullptr;
-    if (!a.index_blob.empty()) {                        // worker: the index the parent built, as the serialized blob
-        FILE* f = fopen(a.index_blob.c_str(), "rb"); if (!f) die("cannot open " + a.index_blob);
-        std::string blob; char buf[1 << 16]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) blob.append(buf, n); fclose(f);
+    if (!a.index_blob.empty() || a.rccl_rank >= 0) {    // worker: the index the parent built, as the serialized blob
+        std::string blob;
+        if (a.rccl_rank <= 0) {                         // (file hand-over, or rank 0 of the RCCL broadcast)
+            FILE* f = fopen(a.index_blob.c_str(), "rb"); if (!f) die("cannot open " + a.index_blob);
+            char buf[1 << 16]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) blob.append(buf, n); fclose(f);
+        }
+        if (a.rccl_rank >= 0) { if (hipSetDevice(a.device) != hipSuccess) die("bad device ordinal"); blob = rccl_broadcast_blob(a.rccl_rank, a.rccl_world, a.rccl_id, blob); }
         if (stitch_index_deserialize(blob.data(), blob.size(), &index) != STITCH_OK) die(stitch_last_error());
     } else if (stitch_index_build(cn.data(), cs.data(), cl.data(), (uint32_t)names.size(), &index) != STITCH_OK) die(stitch_last_error());
 
     if (!a.devices.empty()) {
-        // ---- parent of a multi-device run: no GPU call in this process -----------------------------------------------------
+        // ---- parent of a multi-device run.  NOTHING in this block may call a device function: the workers are started with fork +
+        // exec, and replacing a process that has initialised the GPU takes the machine down on some hosts (the library's host-only
+        // entry points used here — index build / serialize, stitch_shard_range — never touch a device).
         const std::string path = fastq ? a.reads_fastq : a.reads_fasta;
         if (path == "-") die("--devices needs the reads in a file (every worker reads its own block)");
-        std::string cat; std::vector<uint64_t> offs(1, 0);
-        { Rec r; while (reads.next(r)) { cat += r.seq; offs.push_back(cat.size()); } }
-        const uint32_t n_all = (uint32_t)(offs.size() - 1), W = (uint32_t)a.devices.size();
+        // one pass over the reads, nothing kept but 20 bytes per record: where it starts, and (length, hash) to find the read groups
+        std::string surrogate; std::vector<uint64_t> soffs(1, 0); std::vector<long long> rec_at;
+        { Rec r; while (reads.next(r)) { const uint64_t hsh = fnv1a64(r.seq); const uint32_t len = (uint32_t)r.seq.size(); surrogate.append((const char*)&hsh, 8); surrogate.append((const char*)&len, 4);
+                                          soffs.push_back(surrogate.size()); rec_at.push_back(reads.rec_off); } }
+        const uint32_t n_all = (uint32_t)rec_at.size(), W = (uint32_t)a.devices.size();
+        if (a.index_via == "rccl") { std::vector<int> d = a.devices; std::sort(d.begin(), d.end()); if (std::adjacent_find(d.begin(), d.end()) != d.end()) die("--index-via rccl needs one GPU per worker (RCCL refuses two ranks on one device)"); }
+        struct Run {                                    // whatever happens, no worker and no temporary file is left behind
+            std::string dir; std::vector<std::string> files; std::vector<pid_t> pids;
+            ~Run() { for (pid_t p : pids) if (p > 0) { kill(p, SIGTERM); int st; waitpid(p, &st, 0); } for (auto& f : files) unlink(f.c_str()); if (!dir.empty()) rmdir(dir.c_str()); }
+        } run;
         char tmpl[] = "/tmp/stitch-align-XXXXXX"; const char* dir = mkdtemp(tmpl); if (!dir) die("mkdtemp failed");
-        const std::string blob_path = std::string(dir) + "/index.blob";
+        run.dir = dir;
+        const std::string blob_path = run.dir + "/index.blob", id_path = run.dir + "/rccl.id";
+        run.files = {blob_path, id_path, id_path + ".tmp"};
         { size_t len = 0; if (stitch_index_serialize(index, nullptr, &len) != STITCH_OK) die(stitch_last_error()); std::string blob(len, '\0');
           if (stitch_index_serialize(index, &blob[0], &len) != STITCH_OK) die(stitch_last_error());
           FILE* f = fopen(blob_path.c_str(), "wb"); if (!f || fwrite(blob.data(), 1, len, f) != len) die("cannot write " + blob_path); fclose(f); }
-        std::vector<pid_t> pids(W); std::vector<std::string> outs(W);
-        for (uint32_t r = 0; r < W; ++r) {
+        std::vector<std::string> outs(W);
+        for (uint32_t r = 0; r < W; ++r) { outs[r] = run.dir + "/rank" + std::to_string(r) + ".sam"; run.files.push_back(outs[r]); }
+        bool failed = false; std::string why;
+        for (uint32_t r = 0; r < W && !failed; ++r) {
             uint32_t lo = 0, hi = 0;
-            if (stitch_shard_range((const uint8_t*)cat.data(), offs.data(), n_all, W, r, &lo, &hi) != STITCH_OK) die(stitch_last_error());
-            outs[r] = std::string(dir) + "/rank" + std::to_string(r) + ".sam";
+            if (stitch_shard_range((const uint8_t*)surrogate.data(), soffs.data(), n_all, W, r, &lo, &hi) != STITCH_OK) { failed = true; why = stitch_last_error(); break; }
             std::vector<std::string> av;
-            for (int i = 0; i < argc; ++i) { const std::string k = argv[i]; if (k == "--devices" || k == "--output-format") { ++i; continue; } if (k == "--device") { ++i; continue; } av.push_back(k); }
-            av.insert(av.end(), {"--device", std::to_string(a.devices[r]), "--shard", std::to_string(lo), std::to_string(hi), "--shard-out", outs[r], "--index-blob", blob_path});
+            // (the parent's own placement and output options are replaced; none of them has a short spelling, and `--flag=value` is refused by the parser)
+            for (int i = 0; i < argc; ++i) { const std::string k = argv[i]; if (k == "--devices" || k == "--output-format" || k == "--device" || k == "--index-via") { ++i; continue; } av.push_back(k); }
+            av.insert(av.end(), {"--device", std::to_string(a.devices[r]), "--shard", std::to_string(lo), std::to_string(hi), "--shard-offset", std::to_string(lo < n_all ? rec_at[lo] : 0),
+                                 "--shard-out", outs[r], "--index-blob", blob_path});
+            if (a.index_via == "rccl") av.insert(av.end(), {"--rccl", std::to_string(r), std::to_string(W), id_path});
             const pid_t pid = fork();
-            if (pid < 0) die("fork failed");
+            if (pid < 0) { failed = true; why = "fork failed"; break; }
             if (pid == 0) { std::vector<char*> cv; for (auto& x : av) cv.push_back(&x[0]); cv.push_back(nullptr); execv("/proc/self/exe", cv.data()); _exit(127); }
-            pids[r] = pid;
+            run.pids.push_back(pid);
         }
-        bool ok = true;
-        for (uint32_t r = 0; r < W; ++r) { int st = 0; if (waitpid(pids[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; }
-        if (!ok) die("a worker process failed");
+        for (pid_t& p : run.pids) {                     // (after a failure the guard above ends the workers that are still running)
+            if (failed) break;
+            int st = 0; if (waitpid(p, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { failed = true; why = "a worker process failed"; }
+            p = -1;
+        }
+        if (failed) { run.~Run(); run.pids.clear(); run.files.clear(); run.dir.clear(); die(why); }      // (exit() does not unwind: clean up first)
         for (uint32_t r = 0; r < W; ++r) {                 // records in rank order = input order
             LineReader in(outs[r]); std::string l;
             while (in.line(l)) { if (l.empty()) continue; if (out.bam) enc.record(out, l); else { out.put(l.data(), l.size()); out.put("\n", 1); } }
-            unlink(outs[r].c_str());
         }
-        unlink(blob_path.c_str()); rmdir(dir);
         out.finish();
         fprintf(stderr, "stitch-align: %u reads on %u devices\n", n_all, W);
         stitch_index_destroy(index);
@@ -416,6 +501,7 @@ int main(int argc, char** argv) {
         if (!out.bam) fflush(stdout);
     };
     Rec r; long rec_no = 0;
+    if (worker && a.shard_offset > 0) { reads.seek(a.shard_offset); rec_no = a.shard_lo; }      // (no re-parsing of the blocks before this worker's)
     while (reads.next(r)) {
         const long k = rec_no++;
         if (worker && (k < a.shard_lo || k >= a.shard_hi)) { if (k >= a.shard_hi) break; continue; }

@@ -194,3 +194,59 @@ def test_two_worker_processes_write_what_one_device_writes(cli, tmp_path, extra)
     t1, r1, c1 = read_bam(run(cli, "-f", str(fq), "-r", str(ref), "--output-format", "bam", *extra).stdout)
     t2, r2, c2 = read_bam(run(cli, "-f", str(fq), "-r", str(ref), "--output-format", "bam", "--devices", "0,0", *extra).stdout)
     assert r1 == r2 and c1 == c2
+
+
+@pytest.mark.gpu
+def test_workers_seek_to_their_block_in_gzip_fastq_and_multi_line_fasta(cli, tmp_path):
+    """The parent scans the read file once (offset, length and hash per record) and every worker SEEKS to its block instead of
+    parsing the blocks before it: gzip FASTQ (zlib inflates up to the offset) and multi-line FASTA with blank lines (a record's
+    offset is that of its '>' line, read ahead by the record before it) give what one device writes."""
+    import gzip
+    from stitch_amd import synth
+    db = synth.make_db(3, 500, 41)
+    reads = [r.decode() for r in synth.make_reads(db, 23, 180, 19, dup_every=4)]
+    ref = tmp_path / "ref.fa"
+    ref.write_text("".join(f">{n}\n{s.decode()}\n" for n, s in db))
+    fq = tmp_path / "reads.fq.gz"
+    with gzip.open(fq, "wt") as f:
+        f.write("".join(f"@r{k} c\n{r}\n+\n{'I' * len(r)}\n" for k, r in enumerate(reads)))
+    fa = tmp_path / "reads.fa"
+    fa.write_text("".join(f">r{k}\n" + "\n".join(r[p:p + 50] for p in range(0, len(r), 50)) + ("\n\n" if k % 3 == 0 else "\n") for k, r in enumerate(reads)))
+    strip = lambda ls: [l for l in ls if not l.startswith("@PG")]
+    for flag, path in (("-f", fq), ("-a", fa)):
+        one = run(cli, flag, str(path), "-r", str(ref), "--batch", "6").stdout.decode().splitlines()
+        many = run(cli, flag, str(path), "-r", str(ref), "--devices", "0,0,0,0", "--batch", "3").stdout.decode().splitlines()
+        assert strip(one) == strip(many) and len(strip(one)) > len(reads)
+    assert not [p for p in os.listdir("/tmp") if p.startswith("stitch-align-")]          # the temporary directory is gone
+
+
+@pytest.mark.gpu
+def test_a_failing_worker_leaves_nothing_behind(cli, tmp_path):
+    """a worker that cannot start (GPU ordinal that does not exist): the parent reports it, ends the other workers and removes its files"""
+    from stitch_amd import synth
+    db = synth.make_db(2, 300, 5)
+    ref = tmp_path / "ref.fa"; ref.write_text("".join(f">{n}\n{s.decode()}\n" for n, s in db))
+    fq = tmp_path / "r.fq"; fq.write_text("".join(f"@r{k}\n{r.decode()}\n+\n{'I' * len(r)}\n" for k, r in enumerate(synth.make_reads(db, 6, 120, 3))))
+    r = subprocess.run([cli, "-f", str(fq), "-r", str(ref), "--devices", "0,97"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"worker" in r.stderr
+    assert not [p for p in os.listdir("/tmp") if p.startswith("stitch-align-")]
+
+
+@pytest.mark.gpu
+def test_index_broadcast_over_rccl(cli, tmp_path):
+    """`--index-via rccl`: the workers get the reference index through a native ncclBroadcast from rank 0 instead of reading the blob
+    file.  RCCL refuses two ranks on one device, so the one GPU of the test box runs a world of ONE worker here (communicator
+    created from the published unique id, both broadcasts issued); the output must be what the plain run writes."""
+    from stitch_amd import synth
+    db = synth.make_db(3, 400, 8)
+    ref = tmp_path / "ref.fa"; ref.write_text("".join(f">{n}\n{s.decode()}\n" for n, s in db))
+    fq = tmp_path / "r.fq"; fq.write_text("".join(f"@r{k}\n{r.decode()}\n+\n{'I' * len(r)}\n" for k, r in enumerate(synth.make_reads(db, 9, 150, 4))))
+    strip = lambda ls: [l for l in ls if not l.startswith("@PG")]
+    one = run(cli, "-f", str(fq), "-r", str(ref)).stdout.decode().splitlines()
+    r = subprocess.run([cli, "-f", str(fq), "-r", str(ref), "--devices", "0", "--index-via", "rccl"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert b"over RCCL" in r.stderr
+    assert strip(r.stdout.decode().splitlines()) == strip(one)
+    # two ranks on one device: refused up front, with a message (not a hang inside RCCL)
+    r2 = subprocess.run([cli, "-f", str(fq), "-r", str(ref), "--devices", "0,0", "--index-via", "rccl"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r2.returncode != 0 and b"one GPU per worker" in r2.stderr
