@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads-per-step", type=int, default=78, help="reads per GPU per step (78 = two full launches of the register-resident fill: 39 reads x 13 workgroups fill 512 workgroup slots)")
+    ap.add_argument("--reads-per-step", type=int, default=156, help="reads per GPU per step (156 = four full launches of the register-resident fill: 39 reads x 13 workgroups fill 512 workgroup slots; fix-up, walk and downloads of a launch run beside the next launch's fill)")
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--contigs", type=int, default=50)
     ap.add_argument("--contig-len", type=int, default=5000)

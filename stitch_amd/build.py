@@ -42,8 +42,18 @@ def build(force=False, verbose=False):
     objdir = os.path.join(LIB_DIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     procs = []
+    objs = []
+    # an object is rebuilt when its source, a header or the flags changed (fill_regs32.hip alone takes two minutes)
+    stamp = " ".join(common) + repr(sorted(FILE_FLAGS.items()))
+    stamp_path = os.path.join(objdir, "flags.txt")
+    same_flags = os.path.exists(stamp_path) and open(stamp_path).read() == stamp
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     for f in SOURCES:
         obj = os.path.join(objdir, f + ".o")
+        objs.append(obj)
+        if (not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, f))
+                and os.path.getmtime(obj) > newest_header):
+            continue
         cmd = common + FILE_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", obj]
         procs.append((f, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     out, failed = "", []
@@ -54,7 +64,9 @@ def build(force=False, verbose=False):
             failed.append(f)
     if failed:
         raise RuntimeError("hipcc failed on " + ", ".join(failed) + ":\n" + out)
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + [obj for _, obj, _ in procs],
+    with open(stamp_path, "w") as fh:
+        fh.write(stamp)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("linking libstitch_amd.so failed:\n" + r.stdout)

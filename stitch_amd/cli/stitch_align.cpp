@@ -413,7 +413,13 @@ int main(int argc, char** argv) {
             FILE* f = fopen(a.index_blob.c_str(), "rb"); if (!f) die("cannot open " + a.index_blob);
             char buf[1 << 16]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) blob.append(buf, n); fclose(f);
         }
-        if (a.rccl_rank >= 0) { if (hipSetDevice(a.device) != hipSuccess) die("bad device ordinal"); blob = rccl_broadcast_blob(a.rccl_rank, a.rccl_world, a.rccl_id, blob); }
+        if (a.rccl_rank >= 0) {
+            if (hipSetDevice(a.device) != hipSuccess) die("bad device ordinal");
+            // (RCCL announces its version on stdout, which carries the records: its chatter goes to stderr)
+            fflush(stdout); const int saved = dup(1); dup2(2, 1);
+            blob = rccl_broadcast_blob(a.rccl_rank, a.rccl_world, a.rccl_id, blob);
+            fflush(stdout); dup2(saved, 1); close(saved);
+        }
         if (stitch_index_deserialize(blob.data(), blob.size(), &index) != STITCH_OK) die(stitch_last_error());
     } else if (stitch_index_build(cn.data(), cs.data(), cl.data(), (uint32_t)names.size(), &index) != STITCH_OK) die(stitch_last_error());
 
@@ -431,7 +437,8 @@ int main(int argc, char** argv) {
         if (a.index_via == "rccl") { std::vector<int> d = a.devices; std::sort(d.begin(), d.end()); if (std::adjacent_find(d.begin(), d.end()) != d.end()) die("--index-via rccl needs one GPU per worker (RCCL refuses two ranks on one device)"); }
         struct Run {                                    // whatever happens, no worker and no temporary file is left behind
             std::string dir; std::vector<std::string> files; std::vector<pid_t> pids;
-            ~Run() { for (pid_t p : pids) if (p > 0) { kill(p, SIGTERM); int st; waitpid(p, &st, 0); } for (auto& f : files) unlink(f.c_str()); if (!dir.empty()) rmdir(dir.c_str()); }
+            void cleanup() { for (pid_t& p : pids) if (p > 0) { kill(p, SIGTERM); int st; waitpid(p, &st, 0); p = -1; } for (auto& f : files) unlink(f.c_str()); files.clear(); if (!dir.empty()) rmdir(dir.c_str()); dir.clear(); }
+            ~Run() { cleanup(); }
         } run;
         char tmpl[] = "/tmp/stitch-align-XXXXXX"; const char* dir = mkdtemp(tmpl); if (!dir) die("mkdtemp failed");
         run.dir = dir;
@@ -462,7 +469,7 @@ int main(int argc, char** argv) {
             int st = 0; if (waitpid(p, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { failed = true; why = "a worker process failed"; }
             p = -1;
         }
-        if (failed) { run.~Run(); run.pids.clear(); run.files.clear(); run.dir.clear(); die(why); }      // (exit() does not unwind: clean up first)
+        if (failed) { run.cleanup(); die(why); }         // (exit() does not unwind: clean up first)
         for (uint32_t r = 0; r < W; ++r) {                 // records in rank order = input order
             LineReader in(outs[r]); std::string l;
             while (in.line(l)) { if (l.empty()) continue; if (out.bam) enc.record(out, l); else { out.put(l.data(), l.size()); out.put("\n", 1); } }

@@ -52,8 +52,9 @@ bool make_band(const std::vector<Seed>& seeds, uint32_t m, uint32_t n, uint32_t 
     // 2. backbone: best-scoring chain of seeds (k * match per seed, + match for a seed that continues the one a step up the
     //    diagonal, gap penalty -gap_open - gap_extend * d for d = max(query gap, target gap) > 0); first best wins
     const size_t Q = seeds.size();
-    std::vector<long long> best(Q); std::vector<int> from(Q, -1);
+    std::vector<long long> best(Q), prefmax(Q); std::vector<int> from(Q, -1);
     const long long seed_score = (long long)k * match;
+    size_t hi_i = 0;
     for (size_t b = 0; b < Q; ++b) {
         const Seed sb = seeds[b];
         long long v = seed_score; int f = -1;
@@ -62,15 +63,28 @@ bool make_band(const std::vector<Seed>& seeds, uint32_t m, uint32_t n, uint32_t 
             while (lo_ < hi_) { const size_t mid = (lo_ + hi_) / 2; const Seed s = seeds[mid]; if (s.i < sb.i - 1 || (s.i == sb.i - 1 && s.j < sb.j - 1)) lo_ = mid + 1; else hi_ = mid; }
             if (lo_ < b && seeds[lo_].i == sb.i - 1 && seeds[lo_].j == sb.j - 1 && best[lo_] + match > v) { v = best[lo_] + match; f = (int)lo_; }
         }
-        for (size_t a = 0; a < b; ++a) {
+        // Earlier seeds a with sa.i + k <= sb.i and sa.j + k <= sb.j, tried in ascending order, a later one replacing only when strictly
+        // better: the winner is the SMALLEST a among those with the largest candidate.  The literal loop is quadratic in the seeds of
+        // a pair (thousands along a 5 kb segment: the critical path of cfg3's host stage); the same winner is found scanning
+        // DOWNWARDS from the last seed that can precede sb and stopping at the first a whose bound
+        //     prefmax[a] + k * match - pen(gi(a))     (prefmax[a] = largest best[0..a]; every a' <= a has a gap of at least gi(a)
+        //                                              along the read, seeds being ordered by i, and pen grows with the gap)
+        // is below the best candidate found so far: nothing at or before a can reach it, let alone tie.
+        while (hi_i < b && seeds[hi_i].i + k <= sb.i) ++hi_i;          // seeds [0, hi_i) end before sb along the read (sb.i only grows)
+        long long vp = -1; int fp = -1; bool have = false;
+        for (size_t a = hi_i; a-- > 0;) {
             const Seed sa = seeds[a];
-            if (sa.i + k > sb.i) break;                    // seeds are ordered by i: nothing later can precede sb either
+            const long long gi = (long long)sb.i - sa.i - k;
+            const long long bound = prefmax[a] + seed_score - (gi > 0 ? -(long long)gap_open - (long long)gap_extend * gi : 0);
+            if (bound < ((have && vp > v) ? vp : v + 1)) break;      // (a candidate only counts if it beats `v` strictly; once one does, ties with it still matter)
             if (sa.j + k > sb.j) continue;
-            const long long gi = (long long)sb.i - sa.i - k, gj = (long long)sb.j - sa.j - k, d = std::max(gi, gj);
+            const long long gj = (long long)sb.j - sa.j - k, d = std::max(gi, gj);
             const long long cand = best[a] + seed_score - (d > 0 ? -(long long)gap_open - (long long)gap_extend * d : 0);
-            if (cand > v) { v = cand; f = (int)a; }
+            if (!have || cand >= vp) { vp = cand; fp = (int)a; have = true; }      // (>=: of equal candidates the smaller index wins)
         }
+        if (have && vp > v) { v = vp; f = fp; }
         best[b] = v; from[b] = f;
+        prefmax[b] = b > 0 ? std::max(prefmax[b - 1], v) : v;
     }
     size_t end = 0;
     for (size_t b = 1; b < Q; ++b) if (best[b] > best[end]) end = b;

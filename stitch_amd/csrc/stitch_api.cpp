@@ -79,7 +79,7 @@ struct Job {                                     // one full jump DP
 // Diagnostic / experiment knobs, read from the environment ONCE when a context is created (never per launch).
 struct Knobs {
     bool fail_first_attempt = false;             // test hook: treat the first attempt of every cooperative launch as timed out
-    bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false, no_regs32 = false, force_regs32 = false;
+    bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false, no_regs32 = false, force_regs32 = false, no_pipeline = false;
     size_t array_align = 0, job_align = 0;
     std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
@@ -91,6 +91,7 @@ struct Knobs {
         k.fail_first_attempt = getenv("STITCH_TEST_FAIL_FIRST_ATTEMPT") != nullptr;
         k.fill_only = getenv("STITCH_EXP_FILL_ONLY") != nullptr;      // experiment builds whose results are garbage: time the fill, skip the walk
         k.no_regs = getenv("STITCH_NO_REGS") != nullptr;             // keep the state-streaming kernel even where the register-resident one applies
+        k.no_pipeline = getenv("STITCH_NO_PIPELINE") != nullptr;     // one arena window: a launch is finished before the next fill starts
         k.no_regs32 = getenv("STITCH_NO_REGS32") != nullptr;         // keep the generic kernel where the 32-bit register-resident one applies
         k.force_regs32 = getenv("STITCH_FORCE_REGS32") != nullptr;   // (tests) the 32-bit register-resident kernel also where a 16-bit Local-mode kernel applies
         if (const char* e = getenv("STITCH_DUMP_DIR")) k.dump_dir = e;
@@ -119,6 +120,7 @@ struct stitch_ctx {
     uint8_t* arena = nullptr; size_t arena_bytes = 0;     // arena = arena_raw rounded up to a multiple of 1 GiB
     uint8_t* arena_raw = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evp[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};      // per arena window: fill start / end, walk start / end
     // results of the last batch
     std::vector<stitch_read_result> rr; std::vector<stitch_chain> chains; std::vector<stitch_op> ops;
     uint8_t* pin = nullptr;                       // pinned staging buffer for result downloads (PIN_BYTES)
@@ -230,6 +232,7 @@ void stitch_ctx_destroy(stitch_ctx* c) {
     if (c->pin_h2d) (void)hipHostFree(c->pin_h2d);
     for (auto* b : c->pin_bands) if (b) (void)hipHostFree(b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& w : c->evp) for (auto& e : w) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev2) if (e) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -314,6 +317,7 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     HIP_TRY(hipStreamCreate(&c->stream2));
     for (auto& e : c->ev2) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& w : c->evp) for (auto& e : w) HIP_TRY(hipEventCreate(&e));
     if (o->pre_align) {
         c->h_xseq = xseq;
         for (uint32_t a = 0; a < C; ++a) c->strands.push_back(Strand{c->al[a].seqoff, c->al[a].m});
@@ -496,7 +500,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     // 170 ms after the fastest in a 585 ms launch, the same slots every time, whatever read or CUs they get); blocks at
     // multiples of 1 GiB: 505 ms, 128 or 512 MiB: 541, 16 MiB: 695, 1 GiB + 256 KiB: 594.  So: the largest power of two
     // (<= 1 GiB, <= the job size) that still lets the launch window fit the memory.
-    size_t want = 0, block_align = 256;
+    size_t want = 0, block_align = 256, win_jobs = jobs.size();
     for (size_t a = (size_t)1 << 30; a >= 256; a >>= 1) {
         if (a > max_job && a > 256) continue;
         if (c.knobs.job_align) a = std::max<size_t>(256, c.knobs.job_align);      // (experiments)
@@ -525,6 +529,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             for (const Job& jb : jobs) r32_min = std::min(r32_min, regs32_plan(c, jb));
             if (r32_min > 0 && r32_min != 0xFFFFFFFFu) win = std::min<size_t>(jobs.size(), std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs32_wg_per_cu / r32_min));
         }
+        win_jobs = win;
         size_t cur = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
             cur += lay[k].stride + sizeof(JobView) + sizeof(WalkArgs) + 512;
@@ -535,7 +540,12 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         if (want + (1 << 20) <= budget || a == 256 || c.knobs.job_align) break;      // fits (or nothing smaller to try)
     }
     if (c.knobs.debug) fprintf(stderr, "[stitch] job blocks at multiples of %zu bytes, window %zu bytes\n", block_align, want);
-    size_t arena_need = std::min(want + (1 << 20), budget);
+    // Two windows where more than one launch is expected and both fit: the fill of launch k + 1 then runs beside fix-up, walk,
+    // downloads and host parsing of launch k (6 ms of 139 per launch at cfg2, more with --suboptimal's hundreds of chains).
+    const bool quiet = !c.knobs.debug && !c.knobs.profile_dump && !c.knobs.fill_only && c.knobs.dump_dir.empty() && !c.knobs.no_pipeline && !c.knobs.fail_first_attempt;
+    const size_t win_align = std::max<size_t>(block_align, 256);
+    const bool want_two = quiet && jobs.size() > win_jobs && 2 * align_up(want + (1 << 20), win_align) + win_align <= budget;
+    size_t arena_need = std::min(want_two ? 2 * align_up(want + (1 << 20), win_align) : want + (1 << 20), budget);
     if (arena_need > c.arena_bytes) {
         // growing costs seconds (free + allocate: ~5 s for 250 GB), so a context that has to grow takes half as much again
         if (c.arena) arena_need = std::min(budget, arena_need + arena_need / 2);
@@ -559,15 +569,30 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         c.arena_bytes = arena_need;
         if (c.knobs.debug) fprintf(stderr, "[stitch] arena at %p (allocation at %p)\n", (void*)c.arena, (void*)c.arena_raw);
     }
+    // (an arena that was large enough already may hold two windows too)
+    const size_t half = (c.arena_bytes / 2) / win_align * win_align;
+    const bool pipeline = quiet && jobs.size() > win_jobs && half >= want + (1 << 20);
+    const size_t win_bytes = pipeline ? half : c.arena_bytes;
+    if (c.knobs.debug) fprintf(stderr, "[stitch] %s window(s) of %zu bytes\n", pipeline ? "two" : "one", win_bytes);
     FillShared sh{c.d_S0, c.d_Slen0, c.d_Sn0, c.d_SnSet0, c.d_Smove0, c.d_lx0, c.d_base0};
     bool fast = true;
     for (const Job& jb : jobs) if (!local16_ok(c, jb)) { fast = false; break; }
     c.tm_fast = fast;
 
-    size_t k0 = 0;
-    while (k0 < jobs.size()) {
-        // greedy pack of consecutive jobs into the arena
+    // One launch: the jobs [k0, k1) in one window of the arena.  start() packs them, uploads their inputs and launches the fill;
+    // finish() runs fix-up + walk, checks the kernels' error words (and repeats the launch on a fallback kernel once), downloads
+    // the chains.  With two windows the fill of launch k + 1 is started BEFORE launch k is finished: fix-up, walk, downloads and
+    // the host's parsing of launch k then run beside the next fill instead of between two fills.
+    struct Launch {
+        size_t k0 = 0, k1 = 0, win_base = 0; uint32_t nj = 0, regs_G = 0, regs32_G = 0, g_min = 1, G = 1, kind = 0, slots_cap = 0; int waves = 1, slot = 0;
+        std::vector<JobView> views; std::vector<WalkArgs> wargs; std::vector<size_t> base; JobView* d_views = nullptr; WalkArgs* d_wargs = nullptr;
+    };
+    hipStream_t const sA = c.stream, sB = pipeline ? c.stream2 : c.stream;      // sA: the fills, in order; sB: uploads, fix-up + walk, downloads
+    auto start = [&](const size_t k0, const int slot, Launch& Ln) -> int {
+        // greedy pack of consecutive jobs into the window
         size_t k1 = k0, used = 0;
+        const size_t win_base = (size_t)slot * win_bytes;
+        hipEvent_t* const ev = c.evp[slot];
         const size_t view_room = 1 << 20;
         // Local-mode kernel: all G workgroups of all reads of a launch must be resident at once (one workgroup per CU), and a
         // workgroup's slot table holds 2048 tiles.
@@ -593,7 +618,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             if (c.knobs.wg_per_read) max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, (uint32_t)c.knobs.wg_per_read));
         }
         const size_t per_job = sizeof(JobView) + sizeof(WalkArgs) + 512;     // the launch's job table, after the jobs' own buffers
-        while (k1 < jobs.size() && used + lay[k1].stride + per_job + view_room <= c.arena_bytes && (k1 - k0) < max_jobs &&
+        while (k1 < jobs.size() && used + lay[k1].stride + per_job + view_room <= win_bytes && (k1 - k0) < max_jobs &&
                (k1 == k0 || (regs32_G ? regs32_plan(c, jobs[k1]) == regs32_G : (regs_plan(c, jobs[k1]) == regs_G || !fast)))) {
             if (fast && !regs_G && !regs32_G && k1 > k0) {
                 // a later job may need MORE workgroups than the first (shorter read, more contigs): all workgroups of the launch
@@ -605,8 +630,9 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         if (k1 == k0) return fail(STITCH_ENOMEM, "arena too small for one job");
         const uint32_t nj = (uint32_t)(k1 - k0);
-        std::vector<JobView> views(nj); std::vector<WalkArgs> wargs(nj);
-        std::vector<size_t> base(nj);
+        Ln.k0 = k0; Ln.k1 = k1; Ln.nj = nj; Ln.win_base = win_base; Ln.slot = slot; Ln.regs_G = regs_G; Ln.regs32_G = regs32_G;
+        Ln.views.assign(nj, JobView{}); Ln.wargs.assign(nj, WalkArgs{}); Ln.base.assign(nj, 0);
+        std::vector<JobView>& views = Ln.views; std::vector<WalkArgs>& wargs = Ln.wargs; std::vector<size_t>& base = Ln.base;
         int waves = 1;
         auto t_h2d0 = std::chrono::steady_clock::now();
         // the small per-job inputs (read, active contigs, opposite strands, contig table) are contiguous in a job's block:
@@ -622,7 +648,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         size_t o = 0;
         for (uint32_t q = 0; q < nj; ++q) {
             const Job& jb = jobs[k0 + q]; const JobLayout& L = lay[k0 + q];
-            base[q] = o; uint8_t* B = c.arena + o; o += L.stride;
+            base[q] = win_base + o; uint8_t* B = c.arena + win_base + o; o += L.stride;
             waves = std::max(waves, pick_waves(c, L.nact, MAX_WAVES_GENERIC));
             // per-job tables
             std::vector<ContigDesc> cd(c.C); std::vector<int32_t> opp(c.C, -1); std::vector<uint8_t> isact(c.C, 0);
@@ -642,7 +668,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             memcpy(stg + (L.off_act - L.off_y), jb.act.data(), 4ull * L.nact);
             memcpy(stg + (L.off_opp - L.off_y), opp.data(), 4ull * c.C);
             memcpy(stg + (L.off_cd - L.off_y), cd.data(), sizeof(ContigDesc) * (size_t)c.C);
-            HIP_TRY(hipMemcpyAsync(B + L.off_y, stg, L.off_hdr - L.off_y, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(B + L.off_y, stg, L.off_hdr - L.off_y, hipMemcpyHostToDevice, sB));
             JobView& V = views[q];
             V.tb_keyfmt = regs_G ? 2u : regs32_G ? 3u : fast ? 1u : 0u; V.yrec_global = jb.mode == 0 ? 1u : 0u;
             V.P = c.P; V.n = L.n; V.C = c.C; V.nact = L.nact; V.Rtot = L.Rj;
@@ -651,7 +677,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             V.S = (int32_t*)(B + L.off_S); V.Slen = (uint32_t*)(B + L.off_Slen); V.D = (int32_t*)(B + L.off_D); V.Dlen = (uint32_t*)(B + L.off_Dlen);
             V.st16 = (uint32_t*)(B + L.off_st16);
             V.xchg = (unsigned long long*)(B + L.off_xchg); V.err = (uint32_t*)(B + L.off_xchg + 32ull * c.C);
-            HIP_TRY(hipMemsetAsync(B + L.off_xchg, 0, 32ull * c.C + 4096, c.stream));
+            HIP_TRY(hipMemsetAsync(B + L.off_xchg, 0, 32ull * c.C + 4096, sB));
             V.Sn = (int32_t*)(B + L.off_Sn); V.SnLen = (uint32_t*)(B + L.off_SnLen); V.Ly = (uint32_t*)(B + L.off_Ly);
             V.tb = B + L.off_tb; V.Lx = (uint32_t*)(B + L.off_Lx); V.jt_idx = (uint32_t*)(B + L.off_jti); V.jt_from = (uint32_t*)(B + L.off_jtf);
             V.Ival = (int32_t*)(B + L.off_Ival); V.Ilen = (uint32_t*)(B + L.off_Ilen); V.SmoveF = B + L.off_SmoveF;
@@ -662,17 +688,18 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             c.tm.cells += (uint64_t)L.n * [&] { uint64_t s = 0; for (uint32_t a : jb.act) s += c.al[a].m; return s; }();
         }
         // launch-level tables live after the jobs
-        uint8_t* tail = c.arena + align_up(o, 256);
+        uint8_t* tail = c.arena + win_base + align_up(o, 256);
         JobView* d_views = (JobView*)tail; tail += align_up(sizeof(JobView) * nj, 256);
         WalkArgs* d_wargs = (WalkArgs*)tail; tail += align_up(sizeof(WalkArgs) * nj, 256);
-        if ((size_t)(tail - c.arena) > c.arena_bytes) return fail(STITCH_EINTERNAL, "arena overflow");
-        HIP_TRY(hipMemcpyAsync(d_views, views.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(hipMemcpyAsync(d_wargs, wargs.data(), sizeof(WalkArgs) * nj, hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        if ((size_t)(tail - c.arena) > win_base + win_bytes) return fail(STITCH_EINTERNAL, "arena overflow");
+        Ln.d_views = d_views; Ln.d_wargs = d_wargs;
+        HIP_TRY(hipMemcpyAsync(d_views, views.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, sB));
+        HIP_TRY(hipMemcpyAsync(d_wargs, wargs.data(), sizeof(WalkArgs) * nj, hipMemcpyHostToDevice, sB));
+        HIP_TRY(hipStreamSynchronize(sB));              // (the staging buffer is free again; with two windows the fill before this one is still running on sA)
         c.tm.h2d_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h2d0).count();
 
         // Kernel 1 and 2, timed with events on the stream they run on
-        HIP_TRY(hipEventRecord(c.ev[0], c.stream));
+        HIP_TRY(hipEventRecord(ev[0], sA));
         // workgroups per read for the Local-mode kernel: fill the CUs, but keep every workgroup resident at once (they
         // wait for each other every column) and leave each at least a couple of contigs
         uint32_t G = 1;
@@ -717,29 +744,45 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             for (size_t k = 0; k < act.size(); ++k) per[k % G] += (c.al[act[k]].m + 255) / 256;
             for (uint32_t v : per) slots_cap = std::max(slots_cap, v);
         }
+        const uint32_t kind = regs_G ? 2u : regs32_G ? 3u : fast ? 1u : 0u;
+        Ln.G = G; Ln.kind = kind; Ln.waves = waves; Ln.slots_cap = slots_cap; Ln.g_min = g_min;
+        if (kind == 3u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs32(d_views, nj, G, mx, c.opts.circular != 0, sh, sA); }
+        else if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, nj, G, REGS_WAVES, mx, c.opts.circular != 0, sh, sA); }
+        else if (kind == 1u) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, sA);
+        else launch_fill(d_views, nj, waves, sh, sA);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev[1], sA));
+        return STITCH_OK;
+    };
+    auto finish = [&](Launch& Ln) -> int {
+        const size_t k0 = Ln.k0, k1 = Ln.k1; const uint32_t nj = Ln.nj; (void)k1;
+        std::vector<JobView>& views = Ln.views; std::vector<WalkArgs>& wargs = Ln.wargs; std::vector<size_t>& base = Ln.base;
+        JobView* const d_views = Ln.d_views; WalkArgs* const d_wargs = Ln.d_wargs;
+        uint32_t G = Ln.G, slots_cap = Ln.slots_cap, kind = Ln.kind; int waves = Ln.waves;
+        hipEvent_t* const ev = c.evp[Ln.slot];
         // The kernels whose workgroups wait for each other (several workgroups per read) need every workgroup of the launch resident
         // at once.  The grid is sized for that, but another process on the device, CU masking or reserved CUs can break it: the
         // kernels then give up after a bounded wait (error word 1) and the launch is run ONCE more on the streaming kernel with one
         // workgroup per read (nothing waits across workgroups there), or on the generic kernel if a read's tiles exceed one slot table.
-        uint32_t kind = regs_G ? 2u : regs32_G ? 3u : fast ? 1u : 0u;
         for (int attempt = 0;; ++attempt) {
-        if (kind == 3u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs32(d_views, nj, G, mx, c.opts.circular != 0, sh, c.stream); }
-        else if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, nj, G, REGS_WAVES, mx, c.opts.circular != 0, sh, c.stream); }
-        else if (kind == 1u) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, c.stream);
-        else launch_fill(d_views, nj, waves, sh, c.stream);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c.ev[1], c.stream));
-        if (c.knobs.debug) { HIP_TRY(hipStreamSynchronize(c.stream)); fprintf(stderr, "[stitch] fill done (%u jobs, fast=%d)\n", nj, (int)fast); }
+        if (attempt > 0) {      // (the first attempt was launched by start())
+            if (kind == 1u) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, sA);
+            else launch_fill(d_views, nj, waves, sh, sA);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ev[1], sA));
+        }
+        HIP_TRY(hipStreamWaitEvent(sB, ev[1], 0));      // fix-up + walk of this launch: behind its fill, beside the next one
+        if (c.knobs.debug) { HIP_TRY(hipStreamSynchronize(sA)); fprintf(stderr, "[stitch] fill done (%u jobs, fast=%d)\n", nj, (int)fast); }
         if (c.knobs.fill_only) {        // experiment builds (garbage results): the fill's time is all that is wanted
-            HIP_TRY(hipStreamSynchronize(c.stream));
-            float ms_f = 0; HIP_TRY(hipEventElapsedTime(&ms_f, c.ev[0], c.ev[1])); c.tm.fill_ms += ms_f; c.tm.launches += 1; c.tm.jobs += nj;
+            HIP_TRY(hipEventSynchronize(ev[1]));
+            float ms_f = 0; HIP_TRY(hipEventElapsedTime(&ms_f, ev[0], ev[1])); c.tm.fill_ms += ms_f; c.tm.launches += 1; c.tm.jobs += nj;
             if (c.knobs.debug) fprintf(stderr, "[stitch] fill-only launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms\n", nj, G, waves, ms_f);
             break;
         }
         if (!c.knobs.dump_dir.empty()) {
             // debugging aid: what the fill kernel hands to the fix-up kernel (rows of the active contigs in order, roff-indexed), so
             // that two kernels can be compared array by array on the same job
-            HIP_TRY(hipStreamSynchronize(c.stream));
+            HIP_TRY(hipEventSynchronize(ev[1]));
             static int dump_no = 0;
             for (uint32_t q = 0; q < nj; ++q) {
                 const JobLayout& L = lay[k0 + q]; const uint8_t* B = c.arena + base[q];
@@ -759,14 +802,15 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         uint32_t max_nact_mode1 = 0;
         for (uint32_t q = 0; q < nj; ++q) if (jobs[k0 + q].mode == 1) max_nact_mode1 = std::max(max_nact_mode1, lay[k0 + q].nact);
-        launch_fixup_walk(d_views, d_wargs, nj, max_nact_mode1, c.stream);
+        HIP_TRY(hipEventRecord(ev[2], sB));
+        launch_fixup_walk(d_views, d_wargs, nj, max_nact_mode1, sB);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c.ev[2], c.stream));
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        HIP_TRY(hipEventRecord(ev[3], sB));
+        HIP_TRY(hipStreamSynchronize(sB));
         float ms = 0;
         float ms_fill = 0;
-        HIP_TRY(hipEventElapsedTime(&ms_fill, c.ev[0], c.ev[1])); c.tm.fill_ms += ms_fill;
-        HIP_TRY(hipEventElapsedTime(&ms, c.ev[1], c.ev[2])); c.tm.walk_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms_fill, ev[0], ev[1])); c.tm.fill_ms += ms_fill;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); c.tm.walk_ms += ms;
         if (c.knobs.debug) fprintf(stderr, "[stitch] launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms, fix-up + walk %.1f ms\n", nj, G, waves, ms_fill, ms);
         if (attempt == 0) { c.tm.launches += 1; c.tm.jobs += nj; }
         if (c.knobs.profile_dump && (kind == 2u || kind == 3u)) {
@@ -802,14 +846,23 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             for (int w = 0; w < waves; ++w) { fprintf(stderr, "[prof] wave %d:", w); for (int k = 0; k < 8; ++k) { if (k == 2) fprintf(stderr, " tiles=%llu merged=%llu", pf[w * 8 + 2] >> 32, pf[w * 8 + 2] & 0xFFFFFFFFull); else if (k == 1) fprintf(stderr, " simd=%u slot=%u cu=%u", (unsigned)((pf[w * 8 + 1] >> 4) & 3), (unsigned)(pf[w * 8 + 1] & 15), (unsigned)((pf[w * 8 + 1] >> 8) & 15)); else fprintf(stderr, " %s=%.1fM", nm[k], pf[w * 8 + k] / 1e6); } fprintf(stderr, "\n"); }
         }
         if (kind == 2u) {      // the shader clock the fill got (fill_regs.hip leaves it behind the first read's error word)
-            unsigned long long ck[2] = {0, 0}; HIP_TRY(hipMemcpy(ck, (const uint8_t*)views[0].err + ERR_CLOCK_OFF, sizeof(ck), hipMemcpyDeviceToHost));
+            // (copies on sB, never on the null stream: a blocking copy there would wait for the NEXT launch's fill on sA)
+            if (!c.pin) { HIP_TRY(hipHostMalloc((void**)&c.pin, PIN_BYTES, hipHostMallocDefault)); }
+            HIP_TRY(hipMemcpyAsync(c.pin, (const uint8_t*)views[0].err + ERR_CLOCK_OFF, 16, hipMemcpyDeviceToHost, sB));
+            HIP_TRY(hipStreamSynchronize(sB));
+            unsigned long long ck[2]; memcpy(ck, c.pin, 16);
             c.tm.clk_shader_cycles += ck[0]; c.tm.clk_ref_ticks += ck[1];
         }
         bool timed_out = false;
-        if (kind != 0u) for (uint32_t q = 0; q < nj; ++q) {
-            uint32_t e = 0; HIP_TRY(hipMemcpy(&e, views[q].err, 4, hipMemcpyDeviceToHost));
-            if ((e & 0xFFu) == 2u) return fail(STITCH_EINTERNAL, "fill kernel bounds check failed, code " + std::to_string(e >> 8));
-            if (e) timed_out = true;
+        if (kind != 0u) {
+            if (!c.pin) { HIP_TRY(hipHostMalloc((void**)&c.pin, PIN_BYTES, hipHostMallocDefault)); }
+            for (uint32_t q = 0; q < nj; ++q) HIP_TRY(hipMemcpyAsync(c.pin + 4ull * q, views[q].err, 4, hipMemcpyDeviceToHost, sB));
+            HIP_TRY(hipStreamSynchronize(sB));
+            for (uint32_t q = 0; q < nj; ++q) {
+                uint32_t e = 0; memcpy(&e, c.pin + 4ull * q, 4);
+                if ((e & 0xFFu) == 2u) return fail(STITCH_EINTERNAL, "fill kernel bounds check failed, code " + std::to_string(e >> 8));
+                if (e) timed_out = true;
+            }
         }
         if (attempt == 0 && c.knobs.fail_first_attempt && (kind >= 2u || G > 1)) timed_out = true;      // (test hook: exercises the relaunch)
         if (!timed_out) break;
@@ -824,19 +877,19 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             for (uint32_t q = 0; q < nj; ++q) {
                 slots_cap = std::max(slots_cap, local16_wg_tiles(c, jobs[k0 + q], 1));
                 views[q].tb_keyfmt = kind; waves = std::max(waves, pick_waves(c, lay[k0 + q].nact, MAX_WAVES_GENERIC));
-                HIP_TRY(hipMemsetAsync(c.arena + base[q] + lay[k0 + q].off_xchg, 0, 32ull * c.C + 4096, c.stream));
+                HIP_TRY(hipMemsetAsync(c.arena + base[q] + lay[k0 + q].off_xchg, 0, 32ull * c.C + 4096, sA));
             }
             waves = std::min(waves, MAX_WAVES_GENERIC);
             if (kind == 1u) waves = MAX_WAVES_LOCAL;
-            HIP_TRY(hipMemcpyAsync(d_views, views.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(d_views, views.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, sA));
             c.tm.fill_kind = kind; c.tm.wg_per_read = 1; c.tm.fallbacks += 1;
             if (c.knobs.debug) fprintf(stderr, "[stitch] partner timeout: launch of %u jobs repeated with one workgroup per read (kernel kind %u)\n", nj, kind);
-            HIP_TRY(hipEventRecord(c.ev[0], c.stream));
+            HIP_TRY(hipEventRecord(ev[0], sA));
         }
         }
 
 
-        if (c.knobs.fill_only) { k0 = k1; continue; }
+        if (c.knobs.fill_only) return STITCH_OK;
         // download chains: headers first, then the operation lists, both batched through a pinned staging buffer (one
         // synchronous pageable copy per chain costs ~0.15 ms each; --suboptimal yields hundreds of chains per read)
         auto t_d2h0 = std::chrono::steady_clock::now();
@@ -849,10 +902,10 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
                 if (pend[i].bytes > PIN_BYTES) { HIP_TRY(hipMemcpy(pend[i].dst, pend[i].src, pend[i].bytes, hipMemcpyDeviceToHost)); ++i; continue; }
                 size_t used = 0, j = i;
                 while (j < pend.size() && used + pend[j].bytes <= PIN_BYTES) {
-                    HIP_TRY(hipMemcpyAsync(c.pin + used, pend[j].src, pend[j].bytes, hipMemcpyDeviceToHost, c.stream));
+                    HIP_TRY(hipMemcpyAsync(c.pin + used, pend[j].src, pend[j].bytes, hipMemcpyDeviceToHost, sB));
                     used += align_up(pend[j].bytes, 64); ++j;
                 }
-                HIP_TRY(hipStreamSynchronize(c.stream));
+                HIP_TRY(hipStreamSynchronize(sB));
                 used = 0;
                 for (size_t k = i; k < j; ++k) { memcpy(pend[k].dst, c.pin + used, pend[k].bytes); used += align_up(pend[k].bytes, 64); }
                 i = j;
@@ -883,8 +936,8 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
                     Retry rt{}; rt.a.hdr = (ChainHdr*)big; rt.a.ops = (OpRec*)(big + align_up(sizeof(Retry), 256)); rt.a.ops_cap = H.n_ops;
                     rt.a.mode = 2; rt.a.from = H.end_contig_idx; rt.a.skip_fixup = 1;
                     HIP_TRY(hipMemcpy(big, &rt, sizeof(Retry), hipMemcpyHostToDevice));
-                    launch_fixup_walk(d_views + q, (const WalkArgs*)(big + offsetof(Retry, a)), 1, 0, c.stream);
-                    HIP_TRY(hipStreamSynchronize(c.stream));
+                    launch_fixup_walk(d_views + q, (const WalkArgs*)(big + offsetof(Retry, a)), 1, 0, sB);
+                    HIP_TRY(hipStreamSynchronize(sB));
                     HIP_TRY(hipMemcpy(&H, big, sizeof(ChainHdr), hipMemcpyDeviceToHost));
                     ops_src = big + align_up(sizeof(Retry), 256);
                 }
@@ -907,8 +960,19 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         if (int e = flush()) return e;
         c.tm.d2h_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d2h0).count();
-        k0 = k1;
+        return STITCH_OK;
+    };
+    // the launches, in order; with two windows the next fill is started before the last one is finished
+    Launch ring[2]; int pend = -1, no = 0;
+    for (size_t k0 = 0; k0 < jobs.size(); ++no) {
+        const int slot = pipeline ? (no & 1) : 0;
+        if (!pipeline && pend >= 0) { if (int e = finish(ring[pend])) return e; pend = -1; }
+        ring[slot] = Launch();
+        if (int e = start(k0, slot, ring[slot])) return e;
+        if (pend >= 0) { if (int e = finish(ring[pend])) return e; }
+        pend = slot; k0 = ring[slot].k1;
     }
+    if (pend >= 0) { if (int e = finish(ring[pend])) return e; }
     return STITCH_OK;
 }
 

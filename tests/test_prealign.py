@@ -111,7 +111,7 @@ def _bands(x, y, k, w, match=1, go=-6, ge=-2):
     return (full_p, lo.astype(np.uint32), hi.astype(np.uint32)), (full_o, olo, ohi)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(240))
 def test_product_band_equals_oracle_band(seed):
     """the library's host code (sorted k-mer index, analytic diagonal rasterisation) and the oracle's (maps, point by point)
     must produce the same band, column by column: seeds, backbone chain with its tie-breaks, gaps, extensions"""
@@ -132,7 +132,9 @@ def test_product_band_equals_oracle_band(seed):
     k = rng.choice([4, 6, 8, 12]); w = rng.choice([0, 3, 20, 50])
     go, ge = rng.choice([(-6, -2), (0, -1), (-3, -3)])
     p, o = _bands(x, y, k, w, match=rng.choice([1, 2]), go=go, ge=ge)
-    assert p[0] == o[0]
+    # (the library's flag says "no seed: full matrix", the oracle's "the band covers the matrix": a wide band around a real backbone
+    # may cover it too)
+    assert (not p[0]) or o[0]
     assert np.array_equal(p[1], o[1]) and np.array_equal(p[2], o[2])
 
 
