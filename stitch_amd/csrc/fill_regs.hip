@@ -46,7 +46,7 @@ constexpr int AUX_VOLATILE = (int)0x80000000u; // compiler-side: never merged, h
 // In-kernel stamps (diagnostic build only, -DSTITCH_PROFILE): per-wave cycle sums of the column loop's sections, added up per read
 // in the debug area behind V.err.  Never enabled in the product build.
 #ifdef STITCH_PROFILE
-#define RPROF_DECL uint32_t pf_t = (uint32_t)__builtin_readcyclecounter(), pf_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_cnt[2] = {0, 0};
+#define RPROF_DECL uint32_t pf_t = (uint32_t)__builtin_readcyclecounter(), pf_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_cnt[2] = {0, 0}, pf_cls[6] = {0, 0, 0, 0, 0, 0}, pf_c0 = 0, pf_p0 = 0, pf_p1 = 0;
 #define RPROF(k) { const uint32_t pf_n = (uint32_t)__builtin_readcyclecounter(); pf_sum[k] += pf_n - pf_t; pf_t = pf_n; }
 #define RCOUNT(k) pf_cnt[k] += 1u;
 #else
@@ -327,6 +327,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     }
     if (lane == 0) V.Lx[(size_t)c * (n + 1)] = sh.lx0[c];
     int32_t vrun = sh.base0[c].score;                                     // the contig's running maximum over columns < j
+    int32_t cmax_prev = sh.base0[c].score;                                // ... and its maximum in column j-1 alone (what this wave announced)
     // cell (m, j-1), for the zero-cost end-to-start jump of a circular contig (get_jump_score_and_len :258-289)
     const uint32_t trm = cd.troff + m - 1;
     bool rowm_xsuf = sh.Smove0[trm] == TB_XCLIP_SUFFIX; int32_t rowm_S = sh.S0[trm]; uint32_t rowm_len = sh.Slen0[trm];
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     // registers, and re-materialising them costs two instructions per group of rows)
     int32_t MW1v = MW + 1, XW1v = XW + 1; asm volatile("" : "+v"(MW1v), "+v"(XW1v));
     uint32_t ychunk = 0;
+    unsigned long long own_gran = 0ull;                                  // what this wave announced for column j-1 (wave-uniform)
     RPROF_DECL
     // the shader clock this kernel actually gets: s_memtime (shader cycles) against s_memrealtime (100 MHz) over the column loop of
     // each read's first wave, left behind the error word for the host (stitch_timing.clk_*; profiles/clock_probe.sh)
@@ -387,6 +389,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     for (uint32_t j = 1; j <= n; ++j) {
         const bool lastcol = j == n;
         RPROF(7)
+#ifdef STITCH_PROFILE
+        pf_c0 = pf_t;
+#endif
         // ---- poll the team's granules of column j-1 (column 0 came from the host) --------------------------------------------------
         if (j > 1) {
             const uint32_t want = j - 1;
@@ -404,7 +409,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
                     const uint32_t k = (uint32_t)lane_p + 64u * qq;
                     if (k < nact) {
                         const u32x2 g2 = __builtin_amdgcn_raw_buffer_load_b64(rxc, 8u * k, gso, AUX_SC1 | AUX_VOLATILE);
-                        gv[qq] = ((unsigned long long)g2.y << 32) | g2.x; ok &= (g2.y >> 16) == want;
+                        // (the wave's OWN granule is not waited for: it knows what it wrote, and the store's round trip through the
+                        // memory system — microseconds — would sit on the critical path of the one wave the whole team waits for)
+                        gv[qq] = ((unsigned long long)g2.y << 32) | g2.x; ok &= (g2.y >> 16) == want || k == kmine;
                     }
                 }
                 if (__all(ok)) break;
@@ -416,6 +423,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
                 }
                 __builtin_amdgcn_s_sleep(STITCH_POLL_SLEEP);
             }
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq) if ((uint32_t)lane_p + 64u * qq == kmine) gv[qq] = own_gran;
             uint32_t best = 0;
 #pragma unroll
             for (int qq = 0; qq < NQ; ++qq) { const uint32_t sc = (uint32_t)(gv[qq] >> 32) & 0xFFFFu; best = ((uint32_t)lane + 64u * qq < nact && sc > best) ? sc : best; }
@@ -423,6 +432,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
             gmax = colmax > gmax ? colmax : gmax;
         }
         RPROF(0)
+#ifdef STITCH_PROFILE
+        pf_p1 = pf_t; pf_p0 = pf_c0;
+#endif
         // the read's bases, 64 columns per (coalesced) load: lane l holds y[jb + l]
         if (((j - 1) & 63u) == 0) ychunk = (j - 1 + lane < n) ? (uint32_t)yseq[j - 1 + lane] : 0u;
         const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)ychunk, (int)((j - 1) & 63u)) & 0xFFu;
@@ -511,6 +523,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
         // (the smaller of the column's jump words, plus the worse of match and mismatch: a lower bound of every cell's jump candidate)
         const int32_t jw_floor = (word_score(JSW1) < word_score(JSW) ? word_score(JSW1) : word_score(JSW)) + (P.mismatch < P.match ? P.mismatch : P.match);
         const bool may_clip = __builtin_amdgcn_readfirstlane(jw_floor) < 0;
+        // CAN AN INSERTION MATTER IN THIS COLUMN AT ALL?  Every cell of the column is at least its jump candidate (and 0), i.e. >=
+        // tfloor = max(jw_floor, 0).  No cell without its insertion exceeds U = max(this contig's maximum in column j-1, the column's
+        // jump score) + the better of match and mismatch: a diagonal comes from a cell of column j-1, a deletion is never above the
+        // S of its own cell, the jump is the jump.  An insertion chain is an opener S' + go + ge carried down at ge <= 0 per row, so no
+        // chain exceeds U + go + ge; when that is below tfloor no insertion reaches a cell (the merge needs score(I) >= score(S)), there
+        // is no INS move in the column, and the walk reads a column's "I extended" bits only behind one.  Then pass 1b, the scan across
+        // the lanes and pass 2's repair are skipped — for every contig whose column maximum is more than |go + ge| - |mismatch| + match
+        // below the best jump source, i.e. all but the one or two the alignment currently runs in.  (Wave-uniform, exact.)
+        const int32_t jw_top = (word_score(JSW1) > word_score(JSW) ? word_score(JSW1) : word_score(JSW));
+        const int32_t u_top = (cmax_prev > jw_top ? cmax_prev : jw_top) + (P.mismatch > P.match ? P.mismatch : P.match);
+        const bool no_ins = __builtin_amdgcn_readfirstlane((u_top > 0 ? u_top : 0) + kb0 < (jw_floor > 0 ? jw_floor : 0) ? 1 : 0) != 0;
 /* per lane for group 0 only; the other groups under a scalar condition, compared where it is used (kept as twenty boolean masks the
    conditions of a sweep take forty scalar registers) */
 #define GUARD(g) ((g) == 0 ? has0_x : ({ asm volatile("" : "+s"(gtop_x)); (uint32_t)(g) < gtop_x; }))
@@ -525,10 +548,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
 #undef XN
         RPROF(2)
         // ---- pass 1b: the chain of the lane's own openers, merged into the lane's cells; its "extended" bits join the codes in LDS ---
+        int32_t Iin = CHAIN_NONE; uint32_t extin = 0u;
+        bool chains_dead = true;
+        const int32_t tfl = jw_floor > 0 ? jw_floor : 0;                  // every cell of this column is at least this
+        const int32_t live_thr = __builtin_amdgcn_readfirstlane(word_make(tfl, 0)), open_thr = __builtin_amdgcn_readfirstlane(word_make(tfl - kb0, 0));
+        if (!no_ins) {
         Col2 cl;
         cl.GE1 = GE1; cl.GO1 = GO1;
         cl.Iw = CHAIN_NONE; cl.extn = 0u;                                 // nothing arrives at the lane's first row from the lane itself
+        /* ONE test per group whether the chain can matter there at all: a chain is dead once its score is below tfloor (every cell of \
+           the column is >= tfloor, a merge needs score(I) >= score(S), and a chain only decays from row to row unless an opener renews \
+           it), and a cell opens a chain worth following only if score(S') + go + ge >= tfloor.  A group in which no lane carries a live \
+           chain and no lane holds such a cell is left alone: its chain stays dead (the stale word is below tfloor, which is all anybody \
+           asks of it), its "I extended" bits are never read (the walk reads them only behind an INS move, i.e. along a live chain). */ \
 #define P1B(g) if (GUARD(g)) { \
+            const uint32_t h32 = S[4 * (g) + 3] > S[4 * (g) + 2] ? S[4 * (g) + 3] : S[4 * (g) + 2], h10 = S[4 * (g) + 1] > S[4 * (g)] ? S[4 * (g) + 1] : S[4 * (g)]; \
+            const bool hot = (int32_t)(h32 > h10 ? h32 : h10) >= open_thr || cl.Iw >= live_thr; \
+            if (__ballot(hot) != 0ull) { \
             const uint32_t tbl = tbv[g]; \
             uint32_t eb = 0u; \
             const int32_t i3 = chain_row<4 * (g) + 3>(S[4 * (g) + 3], eb, cl), i2 = chain_row<4 * (g) + 2>(S[4 * (g) + 2], eb, cl); \
@@ -541,7 +577,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
                 merge_row<4 * (g) + 3>(S[4 * (g) + 3], tbw, __ballot(m3), i3, bs_lane); merge_row<4 * (g) + 2>(S[4 * (g) + 2], tbw, __ballot(m2), i2, bs_lane); \
                 merge_row<4 * (g) + 1>(S[4 * (g) + 1], tbw, __ballot(m1), i1, bs_lane); merge_row<4 * (g)>(S[4 * (g)], tbw, __ballot(m0), i0, bs_lane); \
             } \
-            tbv[g] = tbw; }
+            tbv[g] = tbw; } }
         REP20(P1B)
 #undef P1B
 #undef GUARD
@@ -552,8 +588,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
         // lanes above — or the opener of row 0 (S' = 0: word GO1 at row 1) — carried down: score + ge per row, length + 1 per row.
         // "Best" = largest score at a common position, earliest lane on ties (the extension wins ties, :321): a prefix maximum
         // of position-normalised keys with the lane as a tag, as in fill_local16.hip.
-        int32_t Iin; uint32_t extin;
-        chain_across_lanes(cl.Iw, cl.extn != 0u, pos_x, gl_x, Iin, extin);
+        // (a chain that leaves its lane dead arrives dead everywhere, and so does row 0's opener, go + ge < 0 <= tfloor: with no live
+        // exit in the wave there is nothing for the scan to carry and nothing for pass 2 to repair)
+        chains_dead = __ballot(cl.Iw >= live_thr) == 0ull;
+        if (!chains_dead) chain_across_lanes(cl.Iw, cl.extn != 0u, pos_x, gl_x, Iin, extin);
+        }
 
         RPROF(4)
         // ---- pass 2: where the arriving chain is alive, its extended bits and its merge (row_alive); per group the lane's running
@@ -587,7 +626,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
             ca.X = Iin; ca.Sup = SUP_NONE; ca.xext = extin;
             // every lane starts in group gtop - 1: the lanes' alive state is scalar from the start, and group_alive runs under scalar
             // conditions with every lane enabled (what it does to a lane that is not alive, or has no group 0, nobody looks at)
-            ca.alive = __ballot(gl > 0);
+            ca.alive = (no_ins || chains_dead) ? 0ull : __ballot(gl > 0 && Iin >= live_thr);      // (a chain that arrives dead stays dead)
             const unsigned long long have0 = __ballot(has0);
 #define P2(g) if (({ asm volatile("" : "+s"(gtop_x)); (uint32_t)(g) < gtop_x; })) { \
             if ((g) == 0) ca.alive &= have0; \
@@ -658,8 +697,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
             const uint32_t smw = (uint32_t)word_make(Sm, Slm);
             // the column arg-max is complete: announce it before the column's remaining work (the other waves wait for nothing else)
             if (Sm > cb_.v) { cb_.v = Sm; cb_.row = m; cb_.len = Slm; }
+            own_gran = ((unsigned long long)j << 48) | ((unsigned long long)(uint32_t)(cb_.v & 0xFFFF) << 32) | ((unsigned long long)((cb_.len + 1u) & 0xFFFFu) << 16) | (cb_.row & 0xFFFFu);
             if (lane == 0) {
-                const unsigned long long gran = ((unsigned long long)j << 48) | ((unsigned long long)(uint32_t)(cb_.v & 0xFFFF) << 32) | ((unsigned long long)((cb_.len + 1u) & 0xFFFFu) << 16) | (cb_.row & 0xFFFFu);
+                const unsigned long long gran = own_gran;
                 u32x2 g2; g2.x = (uint32_t)gran; g2.y = (uint32_t)(gran >> 32);
                 __builtin_amdgcn_raw_buffer_store_b64(g2, rxc, 0u, ((j & 1u) * C + kmine) * 8u, AUX_SC1 | AUX_VOLATILE);   // one aligned 8-byte write, agent scope
             }
@@ -674,6 +714,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
             }
             const uint32_t lx = (do_x_m || xb_.row == 0u) ? 0u : m - xb_.row;
             if (cb_.v > vrun) vrun = cb_.v;
+            cmax_prev = cb_.v;
             rowm_xsuf = mvm == MK_XSUF; rowm_S = Sm; rowm_len = Slm;
             if (mine) {                                     // the register of row m takes the seeded result
                 if (gm == 0) { if (pad == 0) S[0] = smw; else if (pad == 1) S[1] = smw; else if (pad == 2) S[2] = smw; else S[3] = smw; }
@@ -691,6 +732,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
                 Lx[(size_t)c * (n + 1) + j] = lx;
             }
         }
+#ifdef STITCH_PROFILE
+        { const uint32_t pf_e = (uint32_t)__builtin_readcyclecounter(); const int o = no_ins ? 3 : 0; pf_cls[o] += 1u; pf_cls[o + 1] += pf_e - pf_c0; pf_cls[o + 2] += pf_p1 - pf_p0; }
+#endif
     }
     if (kmine == 0 && lane == 0) {
         unsigned long long* const ck = (unsigned long long*)((uint8_t*)V.err + ERR_CLOCK_OFF);
@@ -723,7 +767,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     }
 #ifdef STITCH_PROFILE
     RPROF(6)
-    if (lane == 0) { unsigned long long* const pf = (unsigned long long*)((uint8_t*)V.err + 16); for (int k = 0; k < 8; ++k) atomicAdd(pf + k, (unsigned long long)pf_sum[k]); atomicAdd(pf + 8, 1ull); atomicAdd(pf + 9, (unsigned long long)pf_cnt[0]); atomicAdd(pf + 10, (unsigned long long)pf_cnt[1]); }
+    if (lane == 0) { unsigned long long* const pf = (unsigned long long*)((uint8_t*)V.err + 16); for (int k = 0; k < 8; ++k) atomicAdd(pf + k, (unsigned long long)pf_sum[k]); atomicAdd(pf + 8, 1ull); atomicAdd(pf + 9, (unsigned long long)pf_cnt[0]); atomicAdd(pf + 10, (unsigned long long)pf_cnt[1]); for (int k = 0; k < 6; ++k) atomicAdd(pf + 11 + k, (unsigned long long)pf_cls[k]); }
 #endif
     // ---- unpack the y-suffix records of this wave's rows into the arrays the fix-up kernel reads (its own stores: no barrier) -------
 #pragma unroll 1

@@ -819,7 +819,10 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             static const char* nm3[8] = {"row0+bases", "poll", "jump-select", "pass1", "pass1b", "scan+pass2+tail", "epilogue", "loop-top"};
             const char* const* nm = kind == 2u ? nm2 : nm3;
             for (uint32_t q = 0; q < std::min(nj, 4u); ++q) {
-                unsigned long long pf[11]; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[q].err + 16, sizeof(pf), hipMemcpyDeviceToHost));
+                unsigned long long pf[17] = {0}; HIP_TRY(hipMemcpy(pf, (const uint8_t*)views[q].err + 16, kind == 2u ? sizeof(pf) : 11 * sizeof(pf[0]), hipMemcpyDeviceToHost));
+                if (kind == 2u) fprintf(stderr, "[prof] read %u: columns in which an insertion can matter: %llu wave-columns, %.0f ticks each (poll %.0f); others: %llu, %.0f ticks each (poll %.0f)\n", q,
+                                        pf[11], (double)pf[12] / (double)std::max<unsigned long long>(pf[11], 1), (double)pf[13] / (double)std::max<unsigned long long>(pf[11], 1),
+                                        pf[14], (double)pf[15] / (double)std::max<unsigned long long>(pf[14], 1), (double)pf[16] / (double)std::max<unsigned long long>(pf[14], 1));
                 const double cols = (double)std::max<unsigned long long>(pf[8], 1) * (double)views[q].n;
                 fprintf(stderr, "[prof] read %u: %llu waves;", q, pf[8]);
                 for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.0f", nm[k], (double)pf[k] / cols);
