@@ -94,7 +94,7 @@ long stitch_format_sam(stitch_ctx*, uint32_t read_idx, const char* head, const u
                        size_t n, char* buf, size_t cap);
 
 /* Timing of the last stitch_align_batch on this ctx, measured with HIP events on the stream the kernels ran on:
- * fill_ms = sum over launches of the DP fill kernel, walk_ms = fix-up + traceback kernel, launches = number of
+ * fill_ms = time during which the DP fill kernel was running, walk_ms = fix-up + traceback kernel, launches = number of
  * fill launches, cells = DP cells filled by them.  Used by bench.py for the roofline line. */
 typedef struct stitch_timing { double fill_ms, walk_ms, h2d_ms, d2h_ms, host_ms; uint64_t cells; uint32_t launches; uint32_t jobs;
                                double prealign_ms /* banded kernels incl. their transfers */, prealign_host_ms /* seeds, backbone, band: runs on host
@@ -103,7 +103,10 @@ typedef struct stitch_timing { double fill_ms, walk_ms, h2d_ms, d2h_ms, host_ms;
                                         wg_per_read /* workgroups that shared one read in that launch */,
                                         fallbacks /* launches repeated with one workgroup per read after a partner timeout */, pad_;
                                uint64_t clk_shader_cycles, clk_ref_ticks /* register-resident fill only: shader cycles (s_memtime) and 100 MHz ticks
-                                  (s_memrealtime) over the column loop of the first read of every launch, summed: cycles / ticks x 100 = MHz */; } stitch_timing;
+                                  (s_memrealtime) over the column loop of the first read of every launch, summed: cycles / ticks x 100 = MHz */;
+                               double fill_kernel_ms /* sum of the fill kernels' own durations (what a profiler lists per dispatch).  fill_ms is the time during
+                                  which a fill kernel was RUNNING: with two launches in flight (the next one takes the slots finished reads free) the
+                                  two differ */; } stitch_timing;
 int stitch_last_timing(const stitch_ctx*, stitch_timing* out);
 
 /* Test hook (host only, no device needed): the band of the pre-alignment filter for one (read, target strand) pair as the

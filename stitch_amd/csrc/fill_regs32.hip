@@ -479,10 +479,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         });
         RPROF(3)
         // ---- pass 1b: the chain of the lane's own openers ---------------------------------------------------------------------------------
+        // (as in fill_regs.hip: every cell of the column is at least its jump candidate, >= jw_floor; a chain below that is dead — it can
+        // reach no cell and only decays — and a cell opens a chain worth following only if S' + go + ge >= jw_floor.  A group in which
+        // no lane carries a live chain and no lane holds such a cell is left alone; its "I extended" bits are never read, the walk reads
+        // them only along a live chain.)
         Chain32 cl; cl.ge = ge; cl.goe = goe; cl.Is = CHAIN_NONE32; cl.Il = 0u; cl.extn = 0u;
+        const int32_t open_thr = jw_floor - goe;
         for_groups_down<NG - 1>([&](auto gi) __attribute__((always_inline)) {
             constexpr int g = decltype(gi)::v;
             if (GUARD32(g)) {
+                const int32_t h32 = S[4 * g + 3] > S[4 * g + 2] ? S[4 * g + 3] : S[4 * g + 2], h10 = S[4 * g + 1] > S[4 * g] ? S[4 * g + 1] : S[4 * g];
+                const bool hot = (h32 > h10 ? h32 : h10) >= open_thr || cl.Is >= jw_floor;
+                if (__ballot(hot) == 0ull) return;
                 uint32_t eb = 0u; int32_t i3, i2, i1, i0; uint32_t n3, n2, n1, n0;
                 chain32_row<4 * g + 3>(S[4 * g + 3], L[4 * g + 3], eb, cl, i3, n3); chain32_row<4 * g + 2>(S[4 * g + 2], L[4 * g + 2], eb, cl, i2, n2);
                 chain32_row<4 * g + 1>(S[4 * g + 1], L[4 * g + 1], eb, cl, i1, n1); chain32_row<4 * g>(S[4 * g], L[4 * g], eb, cl, i0, n0);
@@ -496,8 +504,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         });
         RPROF(4)
-        int32_t Iin_s; uint32_t Iin_l, extin;
-        chain_across_lanes(cl.Is, cl.Il, cl.extn != 0u, r0, Iin_s, Iin_l, extin);
+        // (a chain that leaves its lane dead arrives dead everywhere; so does row 0's opener when r0.S + go + ge < jw_floor: then there
+        // is nothing for the scan to carry and nothing for pass 2 to repair)
+        int32_t Iin_s = CHAIN_NONE32; uint32_t Iin_l = 0u, extin = 0u;
+        const bool chains_dead = __ballot(cl.Is >= jw_floor) == 0ull && r0.S + goe < jw_floor;
+        if (!chains_dead) chain_across_lanes(cl.Is, cl.Il, cl.extn != 0u, r0, Iin_s, Iin_l, extin);
 
         // ---- pass 2 + tail: the arriving chain while it is alive; records, y-suffix trackers, the traceback dword -----------------------------
         const gptr<uint32_t> tbcol = (gptr<uint32_t>)as_global(tb0 + (size_t)(j - 1) * Rtot);
@@ -506,7 +517,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const uint32_t ycol = n - j;
         const int32_t ybase = local_mode ? (ymode_global ? gmax : vrun) : rm_run;
         Alive32 ca; ca.ge = ge; ca.goe = goe; ca.Xs = Iin_s; ca.Xl = Iin_l; ca.Sup = CHAIN_NONE32; ca.xext = extin;
-        ca.alive = __ballot(gl > 0);
+        ca.alive = chains_dead ? 0ull : __ballot(gl > 0 && Iin_s >= jw_floor);      // (a chain that arrives dead stays dead)
         const unsigned long long have0 = __ballot(has0);
         for_groups_down<NG - 1>([&](auto gi) __attribute__((always_inline)) {
             constexpr int g = decltype(gi)::v;

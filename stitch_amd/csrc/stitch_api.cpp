@@ -79,7 +79,7 @@ struct Job {                                     // one full jump DP
 // Diagnostic / experiment knobs, read from the environment ONCE when a context is created (never per launch).
 struct Knobs {
     bool fail_first_attempt = false;             // test hook: treat the first attempt of every cooperative launch as timed out
-    bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false, no_regs32 = false, force_regs32 = false, no_pipeline = false;
+    bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false, no_regs32 = false, force_regs32 = false, no_pipeline = false, no_fill_overlap = false;
     size_t array_align = 0, job_align = 0;
     std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
@@ -91,6 +91,7 @@ struct Knobs {
         k.fail_first_attempt = getenv("STITCH_TEST_FAIL_FIRST_ATTEMPT") != nullptr;
         k.fill_only = getenv("STITCH_EXP_FILL_ONLY") != nullptr;      // experiment builds whose results are garbage: time the fill, skip the walk
         k.no_regs = getenv("STITCH_NO_REGS") != nullptr;             // keep the state-streaming kernel even where the register-resident one applies
+        k.no_fill_overlap = getenv("STITCH_NO_FILL_OVERLAP") != nullptr;      // two windows, but a fill starts only when the one before it has ended
         k.no_pipeline = getenv("STITCH_NO_PIPELINE") != nullptr;     // one arena window: a launch is finished before the next fill starts
         k.no_regs32 = getenv("STITCH_NO_REGS32") != nullptr;         // keep the generic kernel where the 32-bit register-resident one applies
         k.force_regs32 = getenv("STITCH_FORCE_REGS32") != nullptr;   // (tests) the 32-bit register-resident kernel also where a 16-bit Local-mode kernel applies
@@ -111,6 +112,7 @@ struct stitch_ctx {
     std::vector<Aligner> al;
     uint32_t C = 0, T = 0, RtotT = 0, max_m = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the banded kernel, concurrent with the full-matrix kernel
+    hipStream_t stream3 = nullptr;                     // the fills of the second arena window (two fills in flight: run_jobs_in_order)
     hipEvent_t ev2[2] = {nullptr, nullptr};
     // device, context lifetime
     uint8_t* d_xseq = nullptr; int32_t* d_S0 = nullptr; uint32_t* d_Slen0 = nullptr; int32_t* d_Sn0 = nullptr;
@@ -235,6 +237,7 @@ void stitch_ctx_destroy(stitch_ctx* c) {
     for (auto& w : c->evp) for (auto& e : w) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev2) if (e) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -315,6 +318,7 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal)); c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipStreamCreate(&c->stream2));
+    HIP_TRY(hipStreamCreate(&c->stream3));
     for (auto& e : c->ev2) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& w : c->evp) for (auto& e : w) HIP_TRY(hipEventCreate(&e));
@@ -587,12 +591,24 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         size_t k0 = 0, k1 = 0, win_base = 0; uint32_t nj = 0, regs_G = 0, regs32_G = 0, g_min = 1, G = 1, kind = 0, slots_cap = 0; int waves = 1, slot = 0;
         std::vector<JobView> views; std::vector<WalkArgs> wargs; std::vector<size_t> base; JobView* d_views = nullptr; WalkArgs* d_wargs = nullptr;
     };
-    hipStream_t const sA = c.stream, sB = pipeline ? c.stream2 : c.stream;      // sA: the fills, in order; sB: uploads, fix-up + walk, downloads
+    // Streams.  sB: uploads, fix-up + walk, downloads.  The fills of window 0 run on c.stream, those of window 1 on c.stream3: the fill of
+    // launch k + 1 is NOT ordered behind the fill of launch k.  The reads of a launch end at different times (an unalignable read keeps
+    // every insertion chain alive, a clean one skips most of that work: 20-30 % apart), and a launch sized to fill the chip holds it
+    // until its slowest read is done; with the next launch already queued, the dispatcher hands every set of workgroup slots a
+    // finished read frees to the next launch's workgroups, in block order — whole teams, since a read's workgroups are consecutive
+    // blocks.  A team that is only partly resident spins (bounded) until the slots it lacks come free, which the older launch
+    // guarantees by running to its end on its own; launch k + 2 shares a stream with launch k and therefore starts only after it, by
+    // which time launch k + 1 has long been fully resident: never more than one launch is left waiting for slots.
+    hipStream_t const sB = pipeline ? c.stream2 : c.stream;
+    const bool overlap_fills = pipeline && !c.knobs.no_fill_overlap;
+    HIP_TRY(hipEventRecord(c.ev[0], c.stream));      // time base of this call's launches
+    double covered_until = 0.0;                      // ms since the base up to which some fill was running
     auto start = [&](const size_t k0, const int slot, Launch& Ln) -> int {
         // greedy pack of consecutive jobs into the window
         size_t k1 = k0, used = 0;
         const size_t win_base = (size_t)slot * win_bytes;
         hipEvent_t* const ev = c.evp[slot];
+        hipStream_t const sA = (overlap_fills && slot == 1) ? c.stream3 : c.stream;
         const size_t view_room = 1 << 20;
         // Local-mode kernel: all G workgroups of all reads of a launch must be resident at once (one workgroup per CU), and a
         // workgroup's slot table holds 2048 tiles.
@@ -760,6 +776,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         JobView* const d_views = Ln.d_views; WalkArgs* const d_wargs = Ln.d_wargs;
         uint32_t G = Ln.G, slots_cap = Ln.slots_cap, kind = Ln.kind; int waves = Ln.waves;
         hipEvent_t* const ev = c.evp[Ln.slot];
+        hipStream_t const sA = (overlap_fills && Ln.slot == 1) ? c.stream3 : c.stream;
         // The kernels whose workgroups wait for each other (several workgroups per read) need every workgroup of the launch resident
         // at once.  The grid is sized for that, but another process on the device, CU masking or reserved CUs can break it: the
         // kernels then give up after a bounded wait (error word 1) and the launch is run ONCE more on the streaming kernel with one
@@ -775,7 +792,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         if (c.knobs.debug) { HIP_TRY(hipStreamSynchronize(sA)); fprintf(stderr, "[stitch] fill done (%u jobs, fast=%d)\n", nj, (int)fast); }
         if (c.knobs.fill_only) {        // experiment builds (garbage results): the fill's time is all that is wanted
             HIP_TRY(hipEventSynchronize(ev[1]));
-            float ms_f = 0; HIP_TRY(hipEventElapsedTime(&ms_f, ev[0], ev[1])); c.tm.fill_ms += ms_f; c.tm.launches += 1; c.tm.jobs += nj;
+            float ms_f = 0; HIP_TRY(hipEventElapsedTime(&ms_f, ev[0], ev[1])); c.tm.fill_ms += ms_f; c.tm.fill_kernel_ms += ms_f; c.tm.launches += 1; c.tm.jobs += nj;
             if (c.knobs.debug) fprintf(stderr, "[stitch] fill-only launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms\n", nj, G, waves, ms_f);
             break;
         }
@@ -808,8 +825,11 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         HIP_TRY(hipEventRecord(ev[3], sB));
         HIP_TRY(hipStreamSynchronize(sB));
         float ms = 0;
-        float ms_fill = 0;
-        HIP_TRY(hipEventElapsedTime(&ms_fill, ev[0], ev[1])); c.tm.fill_ms += ms_fill;
+        float ms_fill = 0, t_start = 0, t_end = 0;
+        HIP_TRY(hipEventElapsedTime(&ms_fill, ev[0], ev[1])); c.tm.fill_kernel_ms += ms_fill;      // this kernel's own duration (what a profiler lists)
+        // fill_ms = the time during which a fill kernel was running: two fills in flight are not counted twice
+        HIP_TRY(hipEventElapsedTime(&t_start, c.ev[0], ev[0])); HIP_TRY(hipEventElapsedTime(&t_end, c.ev[0], ev[1]));
+        { const double a = std::max((double)t_start, covered_until); if ((double)t_end > a) c.tm.fill_ms += (double)t_end - a; covered_until = std::max(covered_until, (double)t_end); }
         HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); c.tm.walk_ms += ms;
         if (c.knobs.debug) fprintf(stderr, "[stitch] launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms, fix-up + walk %.1f ms\n", nj, G, waves, ms_fill, ms);
         if (attempt == 0) { c.tm.launches += 1; c.tm.jobs += nj; }

@@ -54,10 +54,10 @@ def main():
         batch = args.batch or 1000
     elif args.config == "cfg2":
         db = synth.make_db(50, 5000, 1001)
-        n_reads = args.reads or 76
+        n_reads = args.reads or (312 if args.mode == "local" else 152)
         reads = synth.make_reads(db, n_reads, 10000, 44)
         opts = dict(mode=args.mode)
-        batch = args.batch or (78 if args.mode == "local" else 38)        # two launches: 39 reads fill fill_regs' 512 workgroup slots, 19 fill_regs32's 256
+        batch = args.batch or (156 if args.mode == "local" else 76)       # four launches per call: 39 reads fill fill_regs' 512 workgroup slots, 19 fill_regs32's 256
     elif args.config == "cfg3":
         db = synth.make_db(50, 5000, 1001)
         n_reads = args.reads or 512
