@@ -33,9 +33,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SHADER_CLOCK_HZ = 2.4e9    # MI355X_MICROARCH.md "Chip-level parameters": max clock 2400 MHz
-# Integer VALU issue: one wave64 add / max / compare / select per 4 cycles and SIMD, however many waves the SIMD holds —
-# measured on this chip (profiles/ubench/valu_issue.hip -> valu_issue_mi355x.txt: 4.1-4.4 cycles with 2-4 waves, 4.9 with one).
-# MI355X_MICROARCH.md's 2 cycles (SIMD-32) is the v_fma_f32 figure; the integer instructions of the fill do not get it.
+# A conventional yardstick, NOT a ceiling: PMC instruction counts against one wave64 instruction per SIMD and
+# four cycles.  profiles/ubench/valu_issue_mi355x.txt (with control rows): v_fma_f32 / v_add_f32 / v_add_u32 / v_and_b32 / v_mov_b32
+# issue at 2.4-2.7 cycles per SIMD with two or more waves resident (the guide's SIMD-32 figure), v_max / v_cndmask / three-operand and
+# packed instructions at 4.2-4.5, scalar instructions per wave rather than per SIMD, and a lone wave at one instruction per 5 cycles
+# whatever the class.  The fill is bound by the latency between a wave's dependent instructions (a wave issues one per ~9 cycles).
 VALU_CYCLES_PER_WAVE_INST = 4.0
 FILL_KERNELS = {0: "stitch::fill_kernel", 1: "stitch::fill_local16_kernel", 2: "stitch::fill_regs_kernel", 3: "stitch::fill_regs32_kernel"}      # stitch_timing.fill_kind
 KERNEL_SOURCES = ("fill_local16.hip", "fill_regs.hip", "dp_core.h", "walk_core.h", "stitch_api.cpp")
@@ -220,7 +222,7 @@ def main():
                 peak = prop.multi_processor_count * 4 * SHADER_CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST
                 out["roofline"]["valu"] = {"wave_insts_per_64_cells": vpc, "achieved_wave_insts_per_s": vpc * (cells / 64.0) / fill_s,
                                            "peak_wave_insts_per_s": peak, "frac": vpc * (cells / 64.0) / fill_s / peak,
-                                           "peak_source": "CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 integer instruction (measured: profiles/ubench/valu_issue_mi355x.txt)"}
+                                           "peak_source": "yardstick: CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (profiles/ubench/valu_issue_mi355x.txt: 2.4-2.7 cycles for add / and / mov / fma, 4.2-4.5 for max / select / three-operand)"}
                 # ... and every other instruction takes an issue turn of its SIMD as well (two waves per SIMD rarely issue side by side:
                 # both mostly want the vector pipe): all instructions of the kernel against the same one-per-four-cycles peak
                 names = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")
@@ -233,7 +235,8 @@ def main():
                         peak_m = prop.multi_processor_count * 4 * clock_mhz * 1e6 / VALU_CYCLES_PER_WAVE_INST
                         out["roofline"]["issue"]["frac_at_measured_clock"] = ipc * (cells / 64.0) / fill_s / peak_m
                         out["roofline"]["valu"]["frac_at_measured_clock"] = vpc * (cells / 64.0) / fill_s / peak_m
-                out["roofline"]["binding"] = "simd_issue"
+                out["roofline"]["binding"] = ("per-wave instruction latency: neither HBM (1.09 B/cell at the fabric) nor the vector pipe (about 55 % busy) is "
+                                              "saturated; valu / issue below are PMC counts against a conventional one-instruction-per-4-cycles yardstick, not a ceiling")
                 if "SQ_WAVE_CYCLES" in k and "SQ_WAIT_ANY" in k:
                     wc = k["SQ_WAVE_CYCLES"]["avg_per_launch_raw"]
                     out["roofline"]["wave_time_split"] = {n_: k[c_]["avg_per_launch_raw"] / wc for n_, c_ in
