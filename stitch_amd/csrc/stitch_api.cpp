@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <numeric>
 #include <string>
 #include <vector>
 #include <thread>
@@ -35,6 +36,8 @@ bool launch_banded_scores_lds(const BandPair* d_pairs, const uint32_t* d_which, 
 void launch_full_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_full, uint32_t max_m, const BandScoring& sc, const uint8_t* d_reads,
                         const uint8_t* d_contigs, int32_t* d_scores, hipStream_t stream);
 uint32_t full_score_max_rows();
+bool launch_full_scores_skew16(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_full, uint32_t max_m, uint32_t max_n, const BandScoring& sc,
+                               const uint8_t* d_reads, const uint8_t* d_contigs, int32_t* d_scores, hipStream_t stream);
 struct FillShared {
     const int32_t* S0; const uint32_t* Slen0; const int32_t* Sn0; const uint8_t* SnSet0; const uint8_t* Smove0;
     const uint32_t* lx0; const JumpBase* base0;
@@ -79,7 +82,7 @@ struct Job {                                     // one full jump DP
 // Diagnostic / experiment knobs, read from the environment ONCE when a context is created (never per launch).
 struct Knobs {
     bool fail_first_attempt = false;             // test hook: treat the first attempt of every cooperative launch as timed out
-    bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false, no_regs32 = false, force_regs32 = false, no_pipeline = false, no_fill_overlap = false;
+    bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false, no_regs32 = false, force_regs32 = false, no_pipeline = false, no_fill_overlap = false, prealign_v1 = false;
     size_t array_align = 0, job_align = 0;
     std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
@@ -93,6 +96,7 @@ struct Knobs {
         k.no_regs = getenv("STITCH_NO_REGS") != nullptr;             // keep the state-streaming kernel even where the register-resident one applies
         k.no_fill_overlap = getenv("STITCH_NO_FILL_OVERLAP") != nullptr;      // two windows, but a fill starts only when the one before it has ended
         k.no_pipeline = getenv("STITCH_NO_PIPELINE") != nullptr;     // one arena window: a launch is finished before the next fill starts
+        k.prealign_v1 = getenv("STITCH_PREALIGN_V1") != nullptr;     // the pre-alignment's first-generation score kernels (A/B runs, tests)
         k.no_regs32 = getenv("STITCH_NO_REGS32") != nullptr;         // keep the generic kernel where the 32-bit register-resident one applies
         k.force_regs32 = getenv("STITCH_FORCE_REGS32") != nullptr;   // (tests) the 32-bit register-resident kernel also where a 16-bit Local-mode kernel applies
         if (const char* e = getenv("STITCH_DUMP_DIR")) k.dump_dir = e;
@@ -114,6 +118,7 @@ struct stitch_ctx {
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the banded kernel, concurrent with the full-matrix kernel
     hipStream_t stream3 = nullptr;                     // the fills of the second arena window (two fills in flight: run_jobs_in_order)
     hipEvent_t ev2[2] = {nullptr, nullptr};
+    hipEvent_t evc[2] = {nullptr, nullptr};     // pre-alignment: end of the device work of the chunk in each of the two chunk regions
     // device, context lifetime
     uint8_t* d_xseq = nullptr; int32_t* d_S0 = nullptr; uint32_t* d_Slen0 = nullptr; int32_t* d_Sn0 = nullptr;
     uint8_t* d_SnSet0 = nullptr; uint8_t* d_Smove0 = nullptr; uint8_t* d_Imove0 = nullptr; uint32_t* d_lx0 = nullptr;
@@ -236,6 +241,7 @@ void stitch_ctx_destroy(stitch_ctx* c) {
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& w : c->evp) for (auto& e : w) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev2) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->evc) if (e) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -320,6 +326,7 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     HIP_TRY(hipStreamCreate(&c->stream2));
     HIP_TRY(hipStreamCreate(&c->stream3));
     for (auto& e : c->ev2) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : c->evc) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& w : c->evp) for (auto& e : w) HIP_TRY(hipEventCreate(&e));
     if (o->pre_align) {
@@ -1006,20 +1013,47 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
     const uint32_t C = c.C, T = c.T;
     const BandScoring sc{c.opts.match_score, c.opts.mismatch_score, c.opts.gap_open, c.opts.gap_extend};
     has.assign(jobs.size(), 0); score.assign(jobs.size(), 0);
+    if (jobs.empty()) return STITCH_OK;
     auto al256 = [](size_t v) { return (v + 255) / 256 * 256; };
 
-    // chunks of reads: as many as the device scratch holds, and at most PRE_CHUNK, so that a batch makes several chunks and
-    // the host stage of one (seeds, backbone, band: threads) overlaps the device stage of the one before
+    // Device scratch of a call: [reads of every job | pairs | banded scores | full-matrix pairs, ids, scores] for the whole call, then
+    // two chunk regions (bands, id lists, the global-state kernel's state) that alternate.  A read's first base sits at an offset
+    // congruent to 1 modulo 4, so that the word holding the bases of rows 4k .. 4k + 3 (row i compares base i - 1) is aligned.
+    const size_t NJ = jobs.size(), NP = NJ * C;
+    std::vector<uint64_t> q_at(NJ);
+    std::vector<uint8_t> h_reads;
+    uint32_t max_n = 0;
+    for (uint32_t a = 0; a < C; ++a) max_n = std::max(max_n, c.al[a].m);
+    for (size_t k = 0; k < NJ; ++k) {
+        const size_t m = jobs[k].y.size();
+        if (m > 65534) return fail(STITCH_EINVAL, "pre_align: reads longer than 65534 bases are not supported");
+        h_reads.resize((h_reads.size() + 3) / 4 * 4 + 1, 0);
+        q_at[k] = h_reads.size();
+        h_reads.insert(h_reads.end(), jobs[k].y.begin(), jobs[k].y.end());
+    }
+    h_reads.resize(h_reads.size() + 8, 0);
+    uint8_t* p0 = c.pre_buf;
+    uint8_t* d_reads = p0; p0 += al256(h_reads.size());
+    BandPair* d_pairs = (BandPair*)p0; p0 += al256(NP * sizeof(BandPair));
+    int32_t* d_scores = (int32_t*)p0; p0 += al256(NP * 4);
+    BandPair* d_fpairs = (BandPair*)p0; p0 += al256(NP * sizeof(BandPair));
+    uint32_t* d_fids = (uint32_t*)p0; p0 += al256(NP * 4);
+    int32_t* d_fscores = (int32_t*)p0; p0 += al256(NP * 4);
+    const size_t call_bytes = (size_t)(p0 - c.pre_buf);
+    if (call_bytes + 8192 > c.pre_bytes) return fail(STITCH_ENOMEM, "pre_align: the batch does not fit in the pre-alignment scratch (STITCH_PREALIGN_BYTES)");
+    const size_t region_bytes = (c.pre_bytes - call_bytes) / 2 / 256 * 256;
+
+    // chunks of reads: as many as a chunk region holds, and at most PRE_CHUNK, so that a batch makes several chunks and the host
+    // stage of one (seeds, backbone, band: threads) overlaps the device stage of the ones before
     constexpr size_t PRE_CHUNK = 64;
     std::vector<std::pair<size_t, size_t>> chunks;
-    for (size_t k0 = 0; k0 < jobs.size();) {
+    for (size_t k0 = 0; k0 < NJ;) {
         size_t k1 = k0, bytes = 0;
-        while (k1 < jobs.size() && k1 - k0 < PRE_CHUNK) {
+        while (k1 < NJ && k1 - k0 < PRE_CHUNK) {
             const size_t m = jobs[k1].y.size();
-            if (m > 65534) return fail(STITCH_EINVAL, "pre_align: reads longer than 65534 bases are not supported");
-            size_t need = al256(m);
-            for (uint32_t a = 0; a < C; ++a) need += al256(4ull * (c.al[a].m + 1)) + al256(12ull * (m + 1)) + sizeof(BandPair) + 12;
-            if (bytes + need + 4096 > c.pre_bytes) break;
+            size_t need = 0;
+            for (uint32_t a = 0; a < C; ++a) need += al256(4ull * (c.al[a].m + 1)) + al256(12ull * (m + 1)) + 12;
+            if (bytes + need + 4096 > region_bytes) break;
             bytes += need; ++k1;
         }
         if (k1 == k0) return fail(STITCH_ENOMEM, "pre_align: one read does not fit in the pre-alignment scratch (STITCH_PREALIGN_BYTES)");
@@ -1044,20 +1078,16 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
     }
     struct Staged {                                   // what the host stage hands to the device stage
         size_t k0 = 0, k1 = 0;
-        std::vector<uint8_t> h_reads; const uint16_t* bands = nullptr; size_t band_elems = 0; std::vector<BandPair> pairs;
-        std::vector<uint32_t> full_ids, banded_ids, tall_ids; uint32_t full_max_m = 0, banded_max_m = 0; size_t state_elems = 0;   // banded = LDS-ring kernel, tall = global-state kernel
+        const uint16_t* bands = nullptr; size_t band_elems = 0; std::vector<BandPair> pairs;
+        std::vector<uint32_t> full_ids, banded_ids, tall_ids; uint32_t banded_max_m = 0; size_t state_elems = 0;   // ids = pair index in the CALL; banded = LDS-ring kernel, tall = global-state kernel
         double host_ms = 0;
     };
     auto host_stage = [&](size_t k0, size_t k1, uint16_t* bands, Staged& S) {
         auto t_h0 = std::chrono::steady_clock::now();
         const size_t nj = k1 - k0, np = nj * C;
         S.k0 = k0; S.k1 = k1; S.pairs.resize(np); S.bands = bands; S.band_elems = nj * per_read;
-        std::vector<uint64_t> q_off(nj), state_at(nj);
-        for (size_t q = 0; q < nj; ++q) {
-            const Job& jb = jobs[k0 + q];
-            q_off[q] = S.h_reads.size(); S.h_reads.insert(S.h_reads.end(), jb.y.begin(), jb.y.end());
-            state_at[q] = S.state_elems; S.state_elems += (size_t)C * 3ull * (jb.y.size() + 1);
-        }
+        std::vector<uint64_t> state_at(nj);
+        for (size_t q = 0; q < nj; ++q) { state_at[q] = S.state_elems; S.state_elems += (size_t)C * 3ull * (jobs[k0 + q].y.size() + 1); }
         std::vector<uint8_t> full(np, 0);                     // 1 = full matrix, 2 = a band column taller than the LDS ring
         const uint32_t ring = banded_ring_rows();
         // seeds, backbone and band of every pair: independent per read, so the reads are dealt to host threads
@@ -1076,10 +1106,10 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
                     for (uint32_t a = 0; a < C; ++a) {
                         const Aligner& A = c.al[a];
                         BandPair& P = S.pairs[q * C + a];
-                        P.m = m; P.n = A.m; P.q_off = q_off[q]; P.t_off = A.seqoff; P.band_off = 0; P.state_off = 0;
+                        P.m = m; P.n = A.m; P.q_off = q_at[k0 + q]; P.t_off = A.seqoff; P.band_off = 0; P.state_off = 0;
                         const bool is_full = make_band(seeds_[a], m, A.m, (uint32_t)c.opts.kmer_size, (uint32_t)c.opts.band_width,
                                                        c.opts.match_score, c.opts.gap_open, c.opts.gap_extend, lo_, hi_);
-                        if (is_full && m <= full_score_max_rows()) { full[q * C + a] = 1; continue; }                   // register / LDS kernel: no band needed
+                        if (is_full && m <= full_score_max_rows()) { full[q * C + a] = 1; continue; }                   // full-matrix kernels: no band needed
                         P.band_off = q * per_read + a_off[a];
                         P.state_off = state_at[q] + (uint64_t)a * 3ull * (m + 1);
                         for (uint32_t col = 0; col <= A.m; ++col) if (hi_[col] > lo_[col] && (uint32_t)(hi_[col] - lo_[col]) > ring) { full[q * C + a] = 2; break; }
@@ -1095,68 +1125,68 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
             for (auto& th : J.pool) th.join();
             if (failed.load()) throw std::bad_alloc();
         }
+        const uint32_t g0 = (uint32_t)(k0 * C);
         for (size_t k = 0; k < np; ++k) {
-            if (full[k] == 1) { S.full_ids.push_back((uint32_t)k); S.full_max_m = std::max(S.full_max_m, S.pairs[k].m); }
-            else if (full[k] == 2) S.tall_ids.push_back((uint32_t)k);
-            else { S.banded_ids.push_back((uint32_t)k); S.banded_max_m = std::max(S.banded_max_m, S.pairs[k].m); }
+            if (full[k] == 1) S.full_ids.push_back(g0 + (uint32_t)k);
+            else if (full[k] == 2) S.tall_ids.push_back(g0 + (uint32_t)k);
+            else { S.banded_ids.push_back(g0 + (uint32_t)k); S.banded_max_m = std::max(S.banded_max_m, S.pairs[k].m); }
         }
         S.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
     };
-    auto device_stage = [&](Staged& S) -> int {
-        const size_t k0 = S.k0, nj = S.k1 - S.k0, np = nj * C;
-        uint8_t* p = c.pre_buf;
-        uint8_t* d_reads = p; p += al256(S.h_reads.size());
+
+    // Full-matrix pairs collect over the chunks and go out in batches of thousands (one wavefront per pair: a chunk's few
+    // hundred would leave most of the GPU idle), on the context's stream, beside the banded kernels on the second stream.
+    constexpr size_t FULL_BATCH = 8192;
+    std::vector<BandPair> f_pairs; f_pairs.reserve(NP);      // compact copies, in launch order (kept until the end: the uploads are asynchronous)
+    std::vector<uint32_t> f_gid, f_ids;                               // pair index in the call; identity list for the kernels' `which`
+    size_t f_sent = 0;
+    auto flush_full = [&]() -> int {
+        const size_t n = f_pairs.size() - f_sent;
+        if (!n) return STITCH_OK;
+        uint32_t mm = 0, mn = 0;
+        for (size_t k = f_sent; k < f_pairs.size(); ++k) { mm = std::max(mm, f_pairs[k].m); mn = std::max(mn, f_pairs[k].n); }
+        HIP_TRY(hipMemcpyAsync(d_fpairs + f_sent, f_pairs.data() + f_sent, n * sizeof(BandPair), hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemcpyAsync(d_fids + f_sent, f_ids.data() + f_sent, n * 4, hipMemcpyHostToDevice, c.stream));
+        if (c.knobs.prealign_v1 || !launch_full_scores_skew16(d_fpairs, d_fids + f_sent, (uint32_t)n, mm, mn, sc, d_reads, c.d_xseq, d_fscores, c.stream))
+            launch_full_scores(d_fpairs, d_fids + f_sent, (uint32_t)n, mm, sc, d_reads, c.d_xseq, d_fscores, c.stream);
+        HIP_TRY(hipGetLastError());
+        f_sent = f_pairs.size();
+        return STITCH_OK;
+    };
+    f_ids.resize(NP); std::iota(f_ids.begin(), f_ids.end(), 0u);
+
+    auto t_dev0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipMemcpyAsync(d_reads, h_reads.data(), h_reads.size(), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipEventRecord(c.ev2[0], c.stream));
+    HIP_TRY(hipStreamWaitEvent(c.stream2, c.ev2[0], 0));
+    std::vector<Staged> staged(chunks.size());
+    auto device_stage = [&](size_t i) -> int {                       // asynchronous: everything of chunk i on the second stream, then its event
+        Staged& S = staged[i];
+        const size_t np = (S.k1 - S.k0) * C, g0 = S.k0 * C;
+        uint8_t* p = p0 + (i & 1) * region_bytes;
+        uint8_t* const p_end = p + region_bytes;
         uint16_t* d_bands = (uint16_t*)p; p += al256(S.band_elems * 2);
-        BandPair* d_pairs = (BandPair*)p; p += al256(np * sizeof(BandPair));
-        int32_t* d_scores = (int32_t*)p; p += al256(np * 4);
-        uint32_t* d_full = (uint32_t*)p; p += al256(S.full_ids.size() * 4);
         uint32_t* d_banded = (uint32_t*)p; p += al256(S.banded_ids.size() * 4);
         uint32_t* d_tall = (uint32_t*)p; p += al256(S.tall_ids.size() * 4);
         int32_t* d_state = (int32_t*)p; p += al256(S.state_elems * 4);
-        if ((size_t)(p - c.pre_buf) > c.pre_bytes) return fail(STITCH_EINTERNAL, "pre-alignment scratch overflow");
-        auto t_k0 = std::chrono::steady_clock::now();
-        HIP_TRY(hipMemcpyAsync(d_reads, S.h_reads.data(), S.h_reads.size(), hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(hipMemcpyAsync(d_bands, S.bands, S.band_elems * 2, hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(hipMemcpyAsync(d_pairs, S.pairs.data(), np * sizeof(BandPair), hipMemcpyHostToDevice, c.stream));
-        if (!S.full_ids.empty()) HIP_TRY(hipMemcpyAsync(d_full, S.full_ids.data(), S.full_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
-        if (!S.banded_ids.empty()) HIP_TRY(hipMemcpyAsync(d_banded, S.banded_ids.data(), S.banded_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
-        if (!S.tall_ids.empty()) HIP_TRY(hipMemcpyAsync(d_tall, S.tall_ids.data(), S.tall_ids.size() * 4, hipMemcpyHostToDevice, c.stream));
-        // the banded kernels (latency-bound, one wavefront per pair) run on a second stream, concurrently with the full-matrix
-        // kernel (arithmetic-bound): both read the uploads above and write disjoint scores
-        HIP_TRY(hipEventRecord(c.ev2[0], c.stream));
-        HIP_TRY(hipStreamWaitEvent(c.stream2, c.ev2[0], 0));
+        if (p > p_end) return fail(STITCH_EINTERNAL, "pre-alignment scratch overflow");
+        HIP_TRY(hipMemcpyAsync(d_bands, S.bands, S.band_elems * 2, hipMemcpyHostToDevice, c.stream2));
+        HIP_TRY(hipMemcpyAsync(d_pairs + g0, S.pairs.data(), np * sizeof(BandPair), hipMemcpyHostToDevice, c.stream2));
+        if (!S.banded_ids.empty()) HIP_TRY(hipMemcpyAsync(d_banded, S.banded_ids.data(), S.banded_ids.size() * 4, hipMemcpyHostToDevice, c.stream2));
+        if (!S.tall_ids.empty()) HIP_TRY(hipMemcpyAsync(d_tall, S.tall_ids.data(), S.tall_ids.size() * 4, hipMemcpyHostToDevice, c.stream2));
         if (c.knobs.banded_global || !launch_banded_scores_lds(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream2))
             launch_banded_scores(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream2);
         launch_banded_scores(d_pairs, d_tall, (uint32_t)S.tall_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream2);
-        HIP_TRY(hipEventRecord(c.ev2[1], c.stream2));
-        launch_full_scores(d_pairs, d_full, (uint32_t)S.full_ids.size(), S.full_max_m, sc, d_reads, c.d_xseq, d_scores, c.stream);
-        HIP_TRY(hipStreamWaitEvent(c.stream, c.ev2[1], 0));
         HIP_TRY(hipGetLastError());
-        std::vector<int32_t> sco(np);
-        HIP_TRY(hipMemcpyAsync(sco.data(), d_scores, np * 4, hipMemcpyDeviceToHost, c.stream));
-        HIP_TRY(hipStreamSynchronize(c.stream));
-        c.tm.prealign_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_k0).count();
-        for (size_t q = 0; q < nj; ++q) {
-            Job& jb = jobs[k0 + q];
-            std::vector<uint32_t> kept; int32_t best = 0; bool any = false;
-            for (uint32_t t = 0; t < T; ++t) {                                     // targets in order, forward then reverse complement (:249-279)
-                const int32_t f = sco[q * C + t];
-                if (f >= c.opts.pre_align_min_score) { kept.push_back(t); best = any ? std::max(best, f) : f; any = true; }
-                if (c.opts.double_strand) {
-                    const int32_t r = sco[q * C + T + t];
-                    if (r >= c.opts.pre_align_min_score) { kept.push_back(T + t); best = any ? std::max(best, r) : r; any = true; }
-                }
-                if (!c.opts.pre_align_subset_contigs && any) break;                // :276-278
-            }
-            has[k0 + q] = any ? 1 : 0; score[k0 + q] = best;
-            if (any && c.opts.pre_align_subset_contigs) { std::sort(kept.begin(), kept.end()); jb.act = kept; }
-        }
+        HIP_TRY(hipEventRecord(c.evc[i & 1], c.stream2));
+        for (uint32_t g : S.full_ids) { f_gid.push_back(g); f_pairs.push_back(S.pairs[g - g0]); }
+        if (f_pairs.size() - f_sent >= FULL_BATCH) { const int rc = flush_full(); if (rc) return rc; }
         return STITCH_OK;
     };
 
-    // two-stage pipeline: a producer thread stages chunk i + 1 on the host while this thread runs chunk i on the device
-    // (the host stage reads jobs[].y only; the device stage writes jobs[].act of ITS chunk only)
-    std::vector<Staged> staged(chunks.size());
+    // pipeline: a producer thread stages chunk i + 1 on the host while chunk i runs on the device and chunk i - 1 finishes there;
+    // a staging buffer and a chunk region are reused two chunks later, after the event of the chunk that used them
+    // (the host stage reads jobs[].y only)
     std::vector<std::atomic<int>> ready(chunks.size());
     for (auto& r : ready) r.store(0);
     std::atomic<size_t> consumed{0};
@@ -1173,13 +1203,42 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         while (!ready[i].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(100));
         if (ready[i].load() < 0) { rc = fail(STITCH_ENOMEM, "pre_align: out of host memory while building the bands"); break; }
         c.tm.prealign_host_ms += staged[i].host_ms;
-        rc = device_stage(staged[i]);
-        staged[i] = Staged();
-        consumed.store(i + 1);
-        if (rc) { stop.store(true); break; }
+        rc = device_stage(i);
+        if (rc) break;
+        if (i >= 1) {                                                    // chunk i - 1 is done: its staging buffer and region are free for chunk i + 1
+            if (hipEventSynchronize(c.evc[(i - 1) & 1]) != hipSuccess) { rc = fail(STITCH_EINTERNAL, "pre_align: device stage failed"); break; }
+            staged[i - 1].pairs = std::vector<BandPair>();
+        }
+        consumed.store(i);
     }
+    stop.store(true);
     producer.join();
-    return rc;
+    if (!rc) rc = flush_full();
+    const hipError_t e1 = hipStreamSynchronize(c.stream2), e2 = hipStreamSynchronize(c.stream);      // (also on the error paths: nothing of this call stays in flight)
+    if (rc) return rc;
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(STITCH_EINTERNAL, "pre_align: device stage failed");
+    std::vector<int32_t> sco(NP), fsco(f_pairs.size());
+    HIP_TRY(hipMemcpy(sco.data(), d_scores, NP * 4, hipMemcpyDeviceToHost));
+    if (!fsco.empty()) HIP_TRY(hipMemcpy(fsco.data(), d_fscores, fsco.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < f_gid.size(); ++k) sco[f_gid[k]] = fsco[k];
+    c.tm.prealign_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev0).count();
+
+    for (size_t q = 0; q < NJ; ++q) {
+        Job& jb = jobs[q];
+        std::vector<uint32_t> kept; int32_t best = 0; bool any = false;
+        for (uint32_t t = 0; t < T; ++t) {                                     // targets in order, forward then reverse complement (:249-279)
+            const int32_t f = sco[q * C + t];
+            if (f >= c.opts.pre_align_min_score) { kept.push_back(t); best = any ? std::max(best, f) : f; any = true; }
+            if (c.opts.double_strand) {
+                const int32_t r = sco[q * C + T + t];
+                if (r >= c.opts.pre_align_min_score) { kept.push_back(T + t); best = any ? std::max(best, r) : r; any = true; }
+            }
+            if (!c.opts.pre_align_subset_contigs && any) break;                // :276-278
+        }
+        has[q] = any ? 1 : 0; score[q] = best;
+        if (any && c.opts.pre_align_subset_contigs) { std::sort(kept.begin(), kept.end()); jb.act = kept; }
+    }
+    return STITCH_OK;
 }
 
 // traceback_all's selection loop over per-end-contig candidate chains (traceback/mod.rs:152-217)
