@@ -38,6 +38,10 @@ void launch_full_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32
 uint32_t full_score_max_rows();
 bool launch_full_scores_skew16(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_full, uint32_t max_m, uint32_t max_n, const BandScoring& sc,
                                const uint8_t* d_reads, const uint8_t* d_contigs, int32_t* d_scores, hipStream_t stream);
+bool band_fits_window(const uint16_t* lo, const uint16_t* hi, uint32_t m, uint32_t n);
+bool window_scoring_ok(const BandScoring& sc, uint32_t max_m);
+void launch_banded_scores_window(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads,
+                                 const uint8_t* d_contigs, const uint16_t* d_bands, int32_t* d_scores, hipStream_t stream);
 struct FillShared {
     const int32_t* S0; const uint32_t* Slen0; const int32_t* Sn0; const uint8_t* SnSet0; const uint8_t* Smove0;
     const uint32_t* lx0; const JumpBase* base0;
@@ -1052,7 +1056,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         while (k1 < NJ && k1 - k0 < PRE_CHUNK) {
             const size_t m = jobs[k1].y.size();
             size_t need = 0;
-            for (uint32_t a = 0; a < C; ++a) need += al256(4ull * (c.al[a].m + 1)) + al256(12ull * (m + 1)) + 12;
+            for (uint32_t a = 0; a < C; ++a) need += al256(4ull * (c.al[a].m + 1)) + al256(12ull * (m + 1)) + 16;
             if (bytes + need + 4096 > region_bytes) break;
             bytes += need; ++k1;
         }
@@ -1079,7 +1083,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
     struct Staged {                                   // what the host stage hands to the device stage
         size_t k0 = 0, k1 = 0;
         const uint16_t* bands = nullptr; size_t band_elems = 0; std::vector<BandPair> pairs;
-        std::vector<uint32_t> full_ids, banded_ids, tall_ids; uint32_t banded_max_m = 0; size_t state_elems = 0;   // ids = pair index in the CALL; banded = LDS-ring kernel, tall = global-state kernel
+        std::vector<uint32_t> full_ids, win_ids, banded_ids, tall_ids; uint32_t banded_max_m = 0; size_t state_elems = 0;   // ids = pair index in the CALL; win = register-window kernel, banded = LDS-ring kernel, tall = global-state kernel
         double host_ms = 0;
     };
     auto host_stage = [&](size_t k0, size_t k1, uint16_t* bands, Staged& S) {
@@ -1088,7 +1092,8 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         S.k0 = k0; S.k1 = k1; S.pairs.resize(np); S.bands = bands; S.band_elems = nj * per_read;
         std::vector<uint64_t> state_at(nj);
         for (size_t q = 0; q < nj; ++q) { state_at[q] = S.state_elems; S.state_elems += (size_t)C * 3ull * (jobs[k0 + q].y.size() + 1); }
-        std::vector<uint8_t> full(np, 0);                     // 1 = full matrix, 2 = a band column taller than the LDS ring
+        std::vector<uint8_t> full(np, 0);                     // 1 = full matrix, 2 = a band column taller than the LDS ring, 3 = fits the register window
+        const bool win_ok = !c.knobs.prealign_v1 && !c.knobs.banded_global && window_scoring_ok(sc, 65535);
         const uint32_t ring = banded_ring_rows();
         // seeds, backbone and band of every pair: independent per read, so the reads are dealt to host threads
         {
@@ -1112,7 +1117,8 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
                         if (is_full && m <= full_score_max_rows()) { full[q * C + a] = 1; continue; }                   // full-matrix kernels: no band needed
                         P.band_off = q * per_read + a_off[a];
                         P.state_off = state_at[q] + (uint64_t)a * 3ull * (m + 1);
-                        for (uint32_t col = 0; col <= A.m; ++col) if (hi_[col] > lo_[col] && (uint32_t)(hi_[col] - lo_[col]) > ring) { full[q * C + a] = 2; break; }
+                        if (win_ok && band_fits_window(lo_.data(), hi_.data(), m, A.m)) full[q * C + a] = 3;
+                        else for (uint32_t col = 0; col <= A.m; ++col) if (hi_[col] > lo_[col] && (uint32_t)(hi_[col] - lo_[col]) > ring) { full[q * C + a] = 2; break; }
                         memcpy(bands + P.band_off, lo_.data(), sizeof(uint16_t) * (A.m + 1));
                         memcpy(bands + P.band_off + A.m + 1, hi_.data(), sizeof(uint16_t) * (A.m + 1));
                     }
@@ -1129,6 +1135,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         for (size_t k = 0; k < np; ++k) {
             if (full[k] == 1) S.full_ids.push_back(g0 + (uint32_t)k);
             else if (full[k] == 2) S.tall_ids.push_back(g0 + (uint32_t)k);
+            else if (full[k] == 3) S.win_ids.push_back(g0 + (uint32_t)k);
             else { S.banded_ids.push_back(g0 + (uint32_t)k); S.banded_max_m = std::max(S.banded_max_m, S.pairs[k].m); }
         }
         S.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
@@ -1168,12 +1175,17 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         uint16_t* d_bands = (uint16_t*)p; p += al256(S.band_elems * 2);
         uint32_t* d_banded = (uint32_t*)p; p += al256(S.banded_ids.size() * 4);
         uint32_t* d_tall = (uint32_t*)p; p += al256(S.tall_ids.size() * 4);
+        uint32_t* d_win = (uint32_t*)p; p += al256(S.win_ids.size() * 4);
         int32_t* d_state = (int32_t*)p; p += al256(S.state_elems * 4);
         if (p > p_end) return fail(STITCH_EINTERNAL, "pre-alignment scratch overflow");
         HIP_TRY(hipMemcpyAsync(d_bands, S.bands, S.band_elems * 2, hipMemcpyHostToDevice, c.stream2));
         HIP_TRY(hipMemcpyAsync(d_pairs + g0, S.pairs.data(), np * sizeof(BandPair), hipMemcpyHostToDevice, c.stream2));
         if (!S.banded_ids.empty()) HIP_TRY(hipMemcpyAsync(d_banded, S.banded_ids.data(), S.banded_ids.size() * 4, hipMemcpyHostToDevice, c.stream2));
         if (!S.tall_ids.empty()) HIP_TRY(hipMemcpyAsync(d_tall, S.tall_ids.data(), S.tall_ids.size() * 4, hipMemcpyHostToDevice, c.stream2));
+        if (!S.win_ids.empty()) {
+            HIP_TRY(hipMemcpyAsync(d_win, S.win_ids.data(), S.win_ids.size() * 4, hipMemcpyHostToDevice, c.stream2));
+            launch_banded_scores_window(d_pairs, d_win, (uint32_t)S.win_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream2);
+        }
         if (c.knobs.banded_global || !launch_banded_scores_lds(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream2))
             launch_banded_scores(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream2);
         launch_banded_scores(d_pairs, d_tall, (uint32_t)S.tall_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream2);

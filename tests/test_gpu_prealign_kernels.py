@@ -1,5 +1,6 @@
 """The pre-alignment's second-generation score kernels against the oracle's banded scorer, pair by pair:
 
+  banded_score_window_kernel (prealign_window.hip) pairs with a band whose columns fit a window of 256 rows held in registers
   full_score_skew16_kernel (prealign_skew16.hip)  pairs without a k-mer match, scored over the full matrix as an anti-diagonal sweep in
                                                   packed 16-bit words, the target along the rows (128 strips of up to 40 rows)
 
@@ -104,3 +105,77 @@ def test_full_matrix_long_reads_and_many_pairs():
             per += [banded(reads[k], s, k=14), banded(reads[k], s.translate(comp)[::-1], k=14)]
         kept = [v for v in per if v >= 150]
         assert kept and got[k][1] == max(kept), (k, per, got[k][1])
+
+
+# ---- banded_score_window_kernel (prealign_window.hip): the band's rows in a register window of 256 rows ---------------------------
+def noisy(rng, s, sub=0.04, ins=0.02, dele=0.02):
+    out = []
+    for ch in s:
+        r = rng.random()
+        if r < dele:
+            continue
+        out.append(rng.choice("ACGT") if r < dele + sub else ch)
+        if rng.random() < ins:
+            out.append(rng.choice("ACGT"))
+    return "".join(out)
+
+
+def banded_cases(rng, target):
+    n = len(target)
+    reads = [target,                                                               # the diagonal from (0, 0): row 0 in the band of every column
+             noisy(rng, target[n // 3:]),                                          # starts in mid-target: empty columns on the left
+             rnd(rng, 700) + noisy(rng, target[100:n - 200]) + rnd(rng, 500),      # the band far from row 0: the window slides 700 rows before its first column
+             noisy(rng, target[:n // 2], 0.08, 0.04, 0.04),
+             noisy(rng, target[50:400]), target[n - 60:], target[:40],
+             noisy(rng, target[200:900]) + noisy(rng, target[1500:2400]),          # a deletion of 600: the backbone's gap is interpolated, columns taller than the window
+             noisy(rng, target[200:900]) + rnd(rng, 900) + noisy(rng, target[900:1800]),      # an insertion of 900: the window must slide 900 rows at once
+             rnd(rng, 400)]
+    return reads
+
+
+@pytest.mark.parametrize("w", [3, 20, 50, 62, 63, 100])
+def test_banded_pairs_by_band_width(w, monkeypatch):
+    """w <= 62: columns of 4 w + 1 <= 249 rows fit the window; w = 63 and 100 do not, their pairs take the LDS-ring kernel"""
+    rng = random.Random(2000 + w)
+    target = rnd(rng, 3000)
+    reads = banded_cases(rng, target)
+    want = want_of(target, reads, k=10, w=w)
+    assert sum(v > 100 for v in want) >= 6
+    assert scores_of(target, reads, kmer_size=10, band_width=w) == want
+    monkeypatch.setenv("STITCH_PREALIGN_V1", "1")
+    assert scores_of(target, reads, kmer_size=10, band_width=w) == want
+
+
+@pytest.mark.parametrize("sc", [dict(match=2, mismatch=-3, go=-5, ge=-1), dict(match=1, mismatch=-1, go=0, ge=-1), dict(match=5, mismatch=-4, go=-10, ge=-1),
+                                dict(match=1, mismatch=-4, go=-6, ge=0)])
+def test_banded_pairs_other_scorings(sc):
+    rng = random.Random(91)
+    target = rnd(rng, 2500)
+    reads = banded_cases(rng, target)
+    kw = dict(match_score=sc["match"], mismatch_score=sc["mismatch"], gap_open=sc["go"], gap_extend=sc["ge"], kmer_size=10, band_width=40)
+    assert scores_of(target, reads, **kw) == want_of(target, reads, k=10, w=40, **sc)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_banded_pairs_random_shapes(seed):
+    """ragged target and read lengths, several targets on both strands, random k and w: the scores decide which contigs are kept"""
+    rng = random.Random(3000 + seed)
+    targets = [(f"t{k}", rnd(rng, rng.choice([37, 300, 1023, 1024, 2600]))) for k in range(rng.randint(1, 4))]
+    k, w = rng.choice([8, 10, 12]), rng.choice([5, 25, 50, 60])
+    reads = []
+    for _ in range(12):
+        t = rng.choice(targets)[1]
+        a = rng.randrange(0, max(1, len(t) - 30)); b = rng.randrange(a + 1, len(t) + 1)
+        seg = noisy(rng, t[a:b], rng.choice([0.0, 0.03, 0.1]), 0.02, 0.02)
+        reads.append(rnd(rng, rng.choice([0, 0, 5, 300])) + seg + rnd(rng, rng.choice([0, 0, 7, 200])))
+    reads = [r for r in reads if r]
+    opts = dict(pre_align=True, pre_align_min_score=20, kmer_size=k, band_width=w, double_strand=True)
+    al = stitch_amd.Builder(**opts).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in targets], device=0)
+    got = al.align(reads)
+    comp = str.maketrans("ACGT", "TGCA")
+    for i, r in enumerate(reads):
+        per = []
+        for n, s in targets:
+            per += [banded(r, s, k=k, w=w), banded(r, s.translate(comp)[::-1], k=k, w=w)]
+        kept = [v for v in per if v >= 20]
+        assert got[i][1] == (max(kept) if kept else None), (i, per, got[i][1])
