@@ -122,6 +122,7 @@ struct stitch_ctx {
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the banded kernel, concurrent with the full-matrix kernel
     hipStream_t stream3 = nullptr;                     // the fills of the second arena window (two fills in flight: run_jobs_in_order)
     hipEvent_t ev2[2] = {nullptr, nullptr};
+    hipEvent_t evu[2] = {nullptr, nullptr};     // pre-alignment: a chunk's uploads are done
     hipEvent_t evc[2] = {nullptr, nullptr};     // pre-alignment: end of the device work of the chunk in each of the two chunk regions
     // device, context lifetime
     uint8_t* d_xseq = nullptr; int32_t* d_S0 = nullptr; uint32_t* d_Slen0 = nullptr; int32_t* d_Sn0 = nullptr;
@@ -246,6 +247,7 @@ void stitch_ctx_destroy(stitch_ctx* c) {
     for (auto& w : c->evp) for (auto& e : w) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev2) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->evc) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->evu) if (e) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -331,6 +333,7 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     HIP_TRY(hipStreamCreate(&c->stream3));
     for (auto& e : c->ev2) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->evc) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : c->evu) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& w : c->evp) for (auto& e : w) HIP_TRY(hipEventCreate(&e));
     if (o->pre_align) {
@@ -1178,12 +1181,16 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         uint32_t* d_win = (uint32_t*)p; p += al256(S.win_ids.size() * 4);
         int32_t* d_state = (int32_t*)p; p += al256(S.state_elems * 4);
         if (p > p_end) return fail(STITCH_EINTERNAL, "pre-alignment scratch overflow");
-        HIP_TRY(hipMemcpyAsync(d_bands, S.bands, S.band_elems * 2, hipMemcpyHostToDevice, c.stream2));
-        HIP_TRY(hipMemcpyAsync(d_pairs + g0, S.pairs.data(), np * sizeof(BandPair), hipMemcpyHostToDevice, c.stream2));
-        if (!S.banded_ids.empty()) HIP_TRY(hipMemcpyAsync(d_banded, S.banded_ids.data(), S.banded_ids.size() * 4, hipMemcpyHostToDevice, c.stream2));
-        if (!S.tall_ids.empty()) HIP_TRY(hipMemcpyAsync(d_tall, S.tall_ids.data(), S.tall_ids.size() * 4, hipMemcpyHostToDevice, c.stream2));
+        // the uploads (128 MB of band ranges per 64 reads at cfg3) go on a stream of their own, beside the kernels of the chunk before
+        hipStream_t up = c.stream3;
+        HIP_TRY(hipMemcpyAsync(d_bands, S.bands, S.band_elems * 2, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(d_pairs + g0, S.pairs.data(), np * sizeof(BandPair), hipMemcpyHostToDevice, up));
+        if (!S.banded_ids.empty()) HIP_TRY(hipMemcpyAsync(d_banded, S.banded_ids.data(), S.banded_ids.size() * 4, hipMemcpyHostToDevice, up));
+        if (!S.tall_ids.empty()) HIP_TRY(hipMemcpyAsync(d_tall, S.tall_ids.data(), S.tall_ids.size() * 4, hipMemcpyHostToDevice, up));
+        if (!S.win_ids.empty()) HIP_TRY(hipMemcpyAsync(d_win, S.win_ids.data(), S.win_ids.size() * 4, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipEventRecord(c.evu[i & 1], up));
+        HIP_TRY(hipStreamWaitEvent(c.stream2, c.evu[i & 1], 0));
         if (!S.win_ids.empty()) {
-            HIP_TRY(hipMemcpyAsync(d_win, S.win_ids.data(), S.win_ids.size() * 4, hipMemcpyHostToDevice, c.stream2));
             launch_banded_scores_window(d_pairs, d_win, (uint32_t)S.win_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream2);
         }
         if (c.knobs.banded_global || !launch_banded_scores_lds(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream2))
@@ -1226,9 +1233,9 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
     stop.store(true);
     producer.join();
     if (!rc) rc = flush_full();
-    const hipError_t e1 = hipStreamSynchronize(c.stream2), e2 = hipStreamSynchronize(c.stream);      // (also on the error paths: nothing of this call stays in flight)
+    const hipError_t e1 = hipStreamSynchronize(c.stream2), e2 = hipStreamSynchronize(c.stream), e3 = hipStreamSynchronize(c.stream3);      // (also on the error paths: nothing of this call stays in flight)
     if (rc) return rc;
-    if (e1 != hipSuccess || e2 != hipSuccess) return fail(STITCH_EINTERNAL, "pre_align: device stage failed");
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(STITCH_EINTERNAL, "pre_align: device stage failed");
     std::vector<int32_t> sco(NP), fsco(f_pairs.size());
     HIP_TRY(hipMemcpy(sco.data(), d_scores, NP * 4, hipMemcpyDeviceToHost));
     if (!fsco.empty()) HIP_TRY(hipMemcpy(fsco.data(), d_fscores, fsco.size() * 4, hipMemcpyDeviceToHost));

@@ -60,10 +60,10 @@ def main():
         batch = args.batch or (156 if args.mode == "local" else 76)       # four launches per call: 39 reads fill fill_regs' 512 workgroup slots, 19 fill_regs32's 256
     elif args.config == "cfg3":
         db = synth.make_db(50, 5000, 1001)
-        n_reads = args.reads or 512
+        n_reads = args.reads or 2048
         reads = synth.make_reads(db, n_reads, 10000, 45, both_strands=True)
         opts = dict(double_strand=True, pre_align=True, kmer_size=12, band_width=50, pre_align_min_score=100, pre_align_subset_contigs=True)
-        batch = args.batch or 256
+        batch = args.batch or 1024                 # what stitch-align hands over per call
     else:
         db = synth.make_db(200, 5000, 1002)
         n_reads = args.reads or 36
