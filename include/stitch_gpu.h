@@ -115,6 +115,12 @@ int stitch_last_timing(const stitch_ctx*, stitch_timing* out);
 int stitch_prealign_band(const uint8_t* read, uint32_t read_len, const uint8_t* target, uint32_t target_len, uint32_t k, uint32_t w,
                          int32_t match, int32_t gap_open, int32_t gap_extend, uint16_t* lo, uint16_t* hi);
 
+/* The same band as the DEVICE draws it in production (seeds and backbone on the host, the band from the backbone's pieces and the
+ * choice of the score kernel in prealign_band.hip), for the same comparison.  *kernel_class: 0 = LDS-ring kernel, 2 = global-state
+ * kernel, 3 = register-window kernel (only when the band is not the full matrix).  Needs the GPU `device`. */
+int stitch_prealign_band_device(int device, const uint8_t* read, uint32_t read_len, const uint8_t* target, uint32_t target_len, uint32_t k, uint32_t w,
+                                int32_t match, int32_t gap_open, int32_t gap_extend, uint16_t* lo, uint16_t* hi, uint32_t* kernel_class);
+
 /* Multi-GPU sharding of a read stream (host only): the contiguous block [*lo, *hi) of the batch for `rank` of `world` ranks.
  * Blocks are equal shares cut only where two consecutive reads differ, so a run of identical reads — which the reference
  * aligns once (FastxGroupingIterator, align/io.rs:118-146) — stays on one rank; concatenated in rank order the blocks are the

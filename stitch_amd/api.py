@@ -60,7 +60,7 @@ class _Timing(C.Structure):  # == stitch_timing
 
 EXPORTS = ("stitch_opts_default", "stitch_index_build", "stitch_index_serialize", "stitch_index_deserialize",
            "stitch_index_n_contigs", "stitch_index_destroy", "stitch_ctx_create", "stitch_ctx_destroy", "stitch_align_batch",
-           "stitch_format_sam", "stitch_format_sam_chains", "stitch_last_timing", "stitch_prealign_band", "stitch_split_at_y", "stitch_shard_range", "stitch_last_error", "stitch_version")
+           "stitch_format_sam", "stitch_format_sam_chains", "stitch_last_timing", "stitch_prealign_band", "stitch_prealign_band_device", "stitch_split_at_y", "stitch_shard_range", "stitch_last_error", "stitch_version")
 
 _lib = None
 

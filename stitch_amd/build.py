@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libstitch_amd.so")
-SOURCES = ["fill_regs32.hip", "fill_kernel.hip", "fill_local16.hip", "fill_regs.hip", "prealign_kernel.hip", "prealign_skew16.hip", "prealign_window.hip", "stitch_api.cpp", "host_align.cpp", "prealign.cpp"]
+SOURCES = ["fill_regs32.hip", "fill_kernel.hip", "fill_local16.hip", "fill_regs.hip", "prealign_kernel.hip", "prealign_skew16.hip", "prealign_window.hip", "prealign_band.hip", "stitch_api.cpp", "host_align.cpp", "prealign.cpp"]
 HEADERS = ["dp_core.h", "walk_core.h", "fill_common.h", "host_align.h", "prealign.h", os.path.join("..", "..", "include", "stitch_gpu.h")]
 
 

@@ -8,6 +8,8 @@
 namespace stitch {
 
 namespace {
+inline int base2(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+inline uint64_t mix2(uint64_t x) { x ^= x >> 29; x *= 0x9E3779B97F4A7C15ull; x ^= x >> 32; return x; }
 inline uint64_t kmer_hash(const uint8_t* p, uint32_t k) {      // FNV-1a; equality is always re-checked on the bytes
     uint64_t h = 1469598103934665603ull;
     for (uint32_t a = 0; a < k; ++a) { h ^= p[a]; h *= 1099511628211ull; }
@@ -25,6 +27,33 @@ KmerIndex build_kmer_index(const uint8_t* contigs, const std::vector<Strand>& st
     std::sort(es.begin(), es.end(), [](const E& a, const E& b) { return a.h != b.h ? a.h < b.h : a.s != b.s ? a.s < b.s : a.p < b.p; });
     ix.key.resize(es.size()); ix.strand.resize(es.size()); ix.pos.resize(es.size());
     for (size_t a = 0; a < es.size(); ++a) { ix.key[a] = es[a].h; ix.strand[a] = es[a].s; ix.pos[a] = es[a].p; }
+    if (k <= 32) {                                         // the 2-bit accelerator
+        std::vector<E> cs;
+        for (uint32_t s = 0; s < strands.size(); ++s) {
+            uint64_t code = 0; uint32_t good = 0;
+            const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+            for (uint32_t j = 0; j < strands[s].len; ++j) {
+                const int b = base2(contigs[strands[s].off + j]);
+                if (b < 0) { good = 0; code = 0; continue; }
+                code = ((code << 2) | (uint64_t)b) & mask; ++good;
+                if (good >= k) cs.push_back(E{code, s, j + 1 - k});
+            }
+        }
+        std::sort(cs.begin(), cs.end(), [](const E& a, const E& b) { return a.h != b.h ? a.h < b.h : a.s != b.s ? a.s < b.s : a.p < b.p; });
+        size_t distinct = 0;
+        for (size_t a = 0; a < cs.size(); ++a) if (a == 0 || cs[a].h != cs[a - 1].h) ++distinct;
+        size_t cap = 16; while (cap < 2 * distinct + 2) cap <<= 1;
+        ix.t_mask = cap - 1; ix.t_code.assign(cap, 0); ix.t_lo.assign(cap, 0); ix.t_hi.assign(cap, 0);      // an empty slot has t_lo == t_hi
+        ix.c_strand.resize(cs.size()); ix.c_pos.resize(cs.size());
+        for (size_t a = 0; a < cs.size();) {
+            size_t b = a; while (b < cs.size() && cs[b].h == cs[a].h) ++b;
+            uint64_t slot = mix2(cs[a].h) & ix.t_mask;
+            while (ix.t_lo[slot] != ix.t_hi[slot]) slot = (slot + 1) & ix.t_mask;
+            ix.t_code[slot] = cs[a].h; ix.t_lo[slot] = (uint32_t)a; ix.t_hi[slot] = (uint32_t)b;
+            for (size_t e = a; e < b; ++e) { ix.c_strand[e] = cs[e].s; ix.c_pos[e] = cs[e].p; }
+            a = b;
+        }
+    }
     return ix;
 }
 
@@ -33,7 +62,23 @@ void find_seeds(const KmerIndex& ix, const uint8_t* contigs, const std::vector<S
     seeds.assign(strands.size(), {});
     const uint32_t k = ix.k;
     if (k == 0 || m < k || ix.key.empty()) return;
+    const bool fast = ix.t_mask != 0;
+    const uint64_t mask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    uint64_t code = 0; uint32_t good = 0;                  // 2-bit code of the last `good` (capped at k) bases, all of them A / C / G / T
+    for (uint32_t a = 0; fast && a + 1 < k && a < m; ++a) { const int b = base2(q[a]); if (b < 0) { good = 0; code = 0; } else { code = ((code << 2) | (uint64_t)b) & mask; ++good; } }
     for (uint32_t i = 0; i + k <= m; ++i) {
+        if (fast) {
+            const int b = base2(q[i + k - 1]);
+            if (b < 0) { good = 0; code = 0; } else { code = ((code << 2) | (uint64_t)b) & mask; if (good < k) ++good; }
+            if (good >= k) {                                // (a k-mer of four-letter bases only matches k-mers of four-letter bases: all of them are in the table)
+                for (uint64_t slot = mix2(code) & ix.t_mask; ix.t_lo[slot] != ix.t_hi[slot]; slot = (slot + 1) & ix.t_mask) {
+                    if (ix.t_code[slot] != code) continue;
+                    for (uint32_t e = ix.t_lo[slot]; e < ix.t_hi[slot]; ++e) { const uint32_t s = ix.c_strand[e]; if (seeds[s].size() <= MAX_MATCHES) seeds[s].push_back(Seed{i, ix.c_pos[e]}); }
+                    break;
+                }
+                continue;
+            }
+        }
         const uint64_t h = kmer_hash(q + i, k);
         for (auto a = std::lower_bound(ix.key.begin(), ix.key.end(), h); a != ix.key.end() && *a == h; ++a) {
             const size_t e = (size_t)(a - ix.key.begin());
@@ -43,12 +88,10 @@ void find_seeds(const KmerIndex& ix, const uint8_t* contigs, const std::vector<S
     }
 }
 
-bool make_band(const std::vector<Seed>& seeds, uint32_t m, uint32_t n, uint32_t k, uint32_t w, int32_t match, int32_t gap_open,
-               int32_t gap_extend, std::vector<uint16_t>& lo, std::vector<uint16_t>& hi) {
-    lo.assign(n + 1, (uint16_t)(m + 1)); hi.assign(n + 1, 0);
+bool backbone_chain(const std::vector<Seed>& seeds, uint32_t k, int32_t match, int32_t gap_open, int32_t gap_extend, std::vector<uint32_t>& chain) {
+    chain.clear();
     // 1. no seeds, or too many: the band is the full matrix
-    if (seeds.empty() || seeds.size() > MAX_MATCHES) { std::fill(lo.begin(), lo.end(), (uint16_t)0); std::fill(hi.begin(), hi.end(), (uint16_t)(m + 1)); return true; }
-
+    if (seeds.empty() || seeds.size() > MAX_MATCHES) return true;
     // 2. backbone: best-scoring chain of seeds (k * match per seed, + match for a seed that continues the one a step up the
     //    diagonal, gap penalty -gap_open - gap_extend * d for d = max(query gap, target gap) > 0); first best wins
     const size_t Q = seeds.size();
@@ -88,9 +131,24 @@ bool make_band(const std::vector<Seed>& seeds, uint32_t m, uint32_t n, uint32_t 
     }
     size_t end = 0;
     for (size_t b = 1; b < Q; ++b) if (best[b] > best[end]) end = b;
-    std::vector<uint32_t> chain;
     for (int b = (int)end; b >= 0; b = from[b]) chain.push_back((uint32_t)b);
     std::reverse(chain.begin(), chain.end());
+
+    return false;
+}
+
+bool make_band(const std::vector<Seed>& seeds, uint32_t m, uint32_t n, uint32_t k, uint32_t w, int32_t match, int32_t gap_open,
+               int32_t gap_extend, std::vector<uint16_t>& lo, std::vector<uint16_t>& hi) {
+    std::vector<uint32_t> chain;
+    const bool full = backbone_chain(seeds, k, match, gap_open, gap_extend, chain);
+    rasterise_band(seeds, chain, m, n, k, w, lo, hi);
+    return full;
+}
+
+void rasterise_band(const std::vector<Seed>& seeds, const std::vector<uint32_t>& chain, uint32_t m, uint32_t n, uint32_t k, uint32_t w,
+                    std::vector<uint16_t>& lo, std::vector<uint16_t>& hi) {
+    lo.assign(n + 1, (uint16_t)(m + 1)); hi.assign(n + 1, 0);
+    if (chain.empty()) { std::fill(lo.begin(), lo.end(), (uint16_t)0); std::fill(hi.begin(), hi.end(), (uint16_t)(m + 1)); return; }
 
     // 3. band around the backbone: the union of the squares of half-width w around its points
     auto add = [&](long r, long c) {
@@ -113,10 +171,16 @@ bool make_band(const std::vector<Seed>& seeds, uint32_t m, uint32_t n, uint32_t 
     };
     for (size_t p = 0; p < chain.size(); ++p) {
         const Seed s = seeds[chain[p]];
-        add_diag((long)s.i, (long)s.j, (long)k);
+        // seeds that follow each other one step down the diagonal (every position of an exact stretch is a seed) make ONE run: the
+        // union of their squares is the run's
+        size_t e = p;
+        while (e + 1 < chain.size() && seeds[chain[e + 1]].i == seeds[chain[e]].i + 1 && seeds[chain[e + 1]].j == seeds[chain[e]].j + 1) ++e;
+        add_diag((long)s.i, (long)s.j, (long)k + (long)(e - p));
+        p = e;
+        const Seed s_end = seeds[chain[p]];
         if (p + 1 < chain.size()) {
             const Seed nx = seeds[chain[p + 1]];
-            const long ai = (long)s.i + k, aj = (long)s.j + k;
+            const long ai = (long)s_end.i + k, aj = (long)s_end.j + k;
             if ((long)nx.i >= ai && (long)nx.j >= aj) {
                 const long gi = (long)nx.i - ai, gj = (long)nx.j - aj, steps = std::max(gi, gj);
                 for (long a = 1; a < steps; ++a) add(ai + gi * a / steps, aj + gj * a / steps);
@@ -126,7 +190,31 @@ bool make_band(const std::vector<Seed>& seeds, uint32_t m, uint32_t n, uint32_t 
     { const Seed s = seeds[chain.front()]; const long back = (long)std::min(s.i, s.j); add_diag((long)s.i - back, (long)s.j - back, back - 1); }
     { const Seed s = seeds[chain.back()]; const long ie = (long)s.i + k, je = (long)s.j + k;
       add_diag(ie + 1, je + 1, std::min((long)m - ie, (long)n - je) - 1); }
-    return false;
+}
+
+// the calls of rasterise_band as data (same order, same arguments)
+void band_elements(const std::vector<Seed>& seeds, const std::vector<uint32_t>& chain, uint32_t m, uint32_t n, uint32_t k, std::vector<BandElem>& out) {
+    out.clear();
+    if (chain.empty()) return;
+    auto diag = [&](long r, long c, long len) { if (len >= 0) out.push_back(BandElem{(int32_t)r, (int32_t)c, (int32_t)len, -1}); };
+    for (size_t p = 0; p < chain.size(); ++p) {
+        const Seed s = seeds[chain[p]];
+        size_t e = p;
+        while (e + 1 < chain.size() && seeds[chain[e + 1]].i == seeds[chain[e]].i + 1 && seeds[chain[e + 1]].j == seeds[chain[e]].j + 1) ++e;
+        diag((long)s.i, (long)s.j, (long)k + (long)(e - p));
+        p = e;
+        const Seed s_end = seeds[chain[p]];
+        if (p + 1 < chain.size()) {
+            const Seed nx = seeds[chain[p + 1]];
+            const long ai = (long)s_end.i + k, aj = (long)s_end.j + k;
+            if ((long)nx.i >= ai && (long)nx.j >= aj) {
+                const long gi = (long)nx.i - ai, gj = (long)nx.j - aj;
+                if (std::max(gi, gj) >= 2) out.push_back(BandElem{(int32_t)ai, (int32_t)aj, (int32_t)gi, (int32_t)gj});
+            }
+        }
+    }
+    { const Seed s = seeds[chain.front()]; const long back = (long)std::min(s.i, s.j); diag((long)s.i - back, (long)s.j - back, back - 1); }
+    { const Seed s = seeds[chain.back()]; const long ie = (long)s.i + k, je = (long)s.j + k; diag(ie + 1, je + 1, std::min((long)m - ie, (long)n - je) - 1); }
 }
 
 }  // namespace stitch

@@ -18,6 +18,10 @@ struct KmerIndex {
     uint32_t k = 0;
     std::vector<uint64_t> key;
     std::vector<uint32_t> strand, pos;
+    // accelerator for k-mers of A / C / G / T only (k <= 32): their 2-bit codes in an open-addressing table, each with its run
+    // [t_lo, t_hi) of (c_strand, c_pos), ordered as above; a k-mer holding any other byte goes through `key`
+    std::vector<uint64_t> t_code; std::vector<uint32_t> t_lo, t_hi; uint64_t t_mask = 0;
+    std::vector<uint32_t> c_strand, c_pos;
 };
 struct Strand { uint64_t off; uint32_t len; };          // a target strand inside the context's contig buffer
 KmerIndex build_kmer_index(const uint8_t* contigs, const std::vector<Strand>& strands, uint32_t k);
@@ -34,13 +38,29 @@ void find_seeds(const KmerIndex& ix, const uint8_t* contigs, const std::vector<S
 bool make_band(const std::vector<Seed>& seeds, uint32_t m, uint32_t n, uint32_t k, uint32_t w, int32_t match, int32_t gap_open,
                int32_t gap_extend, std::vector<uint16_t>& lo, std::vector<uint16_t>& hi);
 
+// the two halves of make_band: the backbone (indexes into `seeds`, empty = the band is the full matrix: returns true), and the band
+// around it
+bool backbone_chain(const std::vector<Seed>& seeds, uint32_t k, int32_t match, int32_t gap_open, int32_t gap_extend, std::vector<uint32_t>& chain);
+void rasterise_band(const std::vector<Seed>& seeds, const std::vector<uint32_t>& chain, uint32_t m, uint32_t n, uint32_t k, uint32_t w,
+                    std::vector<uint16_t>& lo, std::vector<uint16_t>& hi);
+
+// The band as the device draws it (prealign_band.hip): the backbone as a short list of pieces, each the union of the squares of
+// half-width w around a line of points.
+//   d <  0: the diagonal points (a + t, b + t), t = 0 .. c                      (a run of seeds, the extensions to the matrix edges)
+//   d >= 0: the points (a + c * s / steps, b + d * s / steps), s = 1 .. steps - 1, steps = max(c, d)   (the gap between two runs)
+struct BandElem { int32_t a, b, c, d; };
+void band_elements(const std::vector<Seed>& seeds, const std::vector<uint32_t>& chain, uint32_t m, uint32_t n, uint32_t k, std::vector<BandElem>& out);
+
 // one (read, target strand) pair of a banded launch; offsets are element offsets into the launch's device buffers
 struct BandPair {
     uint32_t m, n;                 // query and target lengths
     uint64_t q_off, t_off;         // query bases (launch buffer), target bases (context's contig buffer)
     uint64_t band_off;             // uint16 lo[n+1] then hi[n+1]
     uint64_t state_off;            // int32 H[2][m+1], D[m+1]
+    uint32_t elem_off, n_elem;     // the pair's band pieces (when the device draws the band)
 };
+// what the band kernel finds: which score kernel takes the pair
+enum : uint32_t { BAND_CLASS_RING = 0, BAND_CLASS_TALL = 2, BAND_CLASS_WINDOW = 3 };
 struct BandScoring { int32_t match, mismatch, gap_open, gap_extend; };
 
 }  // namespace stitch

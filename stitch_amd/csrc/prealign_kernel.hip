@@ -27,8 +27,10 @@ __device__ __forceinline__ int32_t floor_min(long long v) { return v < (long lon
 
 __global__ __launch_bounds__(64) void banded_score_kernel(const BandPair* __restrict__ pairs, const uint32_t* __restrict__ which, BandScoring sc,
                                                           const uint8_t* __restrict__ reads, const uint8_t* __restrict__ contigs,
-                                                          const uint16_t* __restrict__ bands, int32_t* __restrict__ state, int32_t* __restrict__ scores) {
+                                                          const uint16_t* __restrict__ bands, int32_t* __restrict__ state, int32_t* __restrict__ scores,
+                                                          const uint32_t* __restrict__ cls, uint32_t my_class) {
     const uint32_t pid = which[blockIdx.x];
+    if (cls && cls[pid] != my_class) return;                           // (the device drew the bands and chose the kernels: prealign_band.hip)
     const BandPair P = pairs[pid];
     const int lane = threadIdx.x;
     const uint32_t m = P.m, n = P.n;
@@ -101,9 +103,10 @@ __device__ __forceinline__ int32_t dpp_max_shr(int32_t v, int32_t none) {       
 }
 __global__ __launch_bounds__(64) void banded_score_lds_kernel(const BandPair* __restrict__ pairs, const uint32_t* __restrict__ which, BandScoring sc,
                                                               const uint8_t* __restrict__ reads, const uint8_t* __restrict__ contigs,
-                                                              const uint16_t* __restrict__ bands, int32_t* __restrict__ scores) {
+                                                              const uint16_t* __restrict__ bands, int32_t* __restrict__ scores, const uint32_t* __restrict__ cls) {
     extern __shared__ int32_t band_lds[];
     const uint32_t pid = which[blockIdx.x];
+    if (cls && cls[pid] != BAND_CLASS_RING) return;
     const BandPair P = pairs[pid];
     const int lane = threadIdx.x;
     const uint32_t m = P.m, n = P.n;
@@ -322,20 +325,20 @@ void launch_full_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32
 uint32_t full_score_max_rows() { return FULL_MAX_ROWS; }
 
 void launch_banded_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
-                          const uint16_t* d_bands, int32_t* d_state, int32_t* d_scores, hipStream_t stream) {
-    if (n_pairs) hipLaunchKernelGGL(banded_score_kernel, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_bands, d_state, d_scores);
+                          const uint16_t* d_bands, int32_t* d_state, int32_t* d_scores, const uint32_t* d_cls, uint32_t my_class, hipStream_t stream) {
+    if (n_pairs) hipLaunchKernelGGL(banded_score_kernel, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_bands, d_state, d_scores, d_cls, my_class);
 }
 // pairs whose band columns are at most banded_ring_rows() tall and whose reads are at most max_m long; false = not applicable
 // (scores or keys do not fit 32 bits, or the read does not fit in LDS): the caller uses launch_banded_scores for them too
 uint32_t banded_ring_rows() { return BAND_RING; }
 bool launch_banded_scores_lds(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, uint32_t max_m, const BandScoring& sc, const uint8_t* d_reads,
-                              const uint8_t* d_contigs, const uint16_t* d_bands, int32_t* d_scores, hipStream_t stream) {
+                              const uint8_t* d_contigs, const uint16_t* d_bands, int32_t* d_scores, const uint32_t* d_cls, hipStream_t stream) {
     const long long big = (long long)1 << 29;
     const bool small = (long long)std::abs(sc.match) * (max_m + 1) < big && (long long)std::abs(sc.gap_extend) * (max_m + 2) + std::abs(sc.gap_open) < big &&
                        std::abs((long long)sc.mismatch) < big && sc.gap_extend <= 0 && sc.gap_open <= 0;
     const size_t lds = (size_t)BAND_RING * 12 + ((size_t)max_m + 3) / 4 * 4;
     if (!small || lds > BAND_LDS_MAX) return false;
-    if (n_pairs) hipLaunchKernelGGL(banded_score_lds_kernel, dim3(n_pairs), dim3(64), lds, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_bands, d_scores);
+    if (n_pairs) hipLaunchKernelGGL(banded_score_lds_kernel, dim3(n_pairs), dim3(64), lds, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_bands, d_scores, d_cls);
     return true;
 }
 

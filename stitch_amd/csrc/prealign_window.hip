@@ -43,8 +43,9 @@ __device__ __forceinline__ int32_t from_lane_below(int32_t v, int32_t last) {   
 
 __global__ __launch_bounds__(64) void banded_score_window_kernel(const BandPair* __restrict__ pairs, const uint32_t* __restrict__ which, BandScoring sc,
                                                                  const uint8_t* __restrict__ reads, const uint8_t* __restrict__ contigs,
-                                                                 const uint16_t* __restrict__ bands, int32_t* __restrict__ scores) {
+                                                                 const uint16_t* __restrict__ bands, int32_t* __restrict__ scores, const uint32_t* __restrict__ cls) {
     const uint32_t pid = which[blockIdx.x];
+    if (cls && cls[pid] != BAND_CLASS_WINDOW) return;                    // (the device drew the bands and chose the kernels: prealign_band.hip)
     const BandPair P = pairs[pid];
     const uint32_t lane = threadIdx.x;
     const uint32_t m = P.m, n = P.n;
@@ -144,8 +145,8 @@ bool window_scoring_ok(const BandScoring& sc, uint32_t max_m) {
            std::abs((long long)sc.mismatch) < big && sc.gap_extend <= 0 && sc.gap_open <= 0;
 }
 void launch_banded_scores_window(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads,
-                                 const uint8_t* d_contigs, const uint16_t* d_bands, int32_t* d_scores, hipStream_t stream) {
-    if (n_pairs) hipLaunchKernelGGL(banded_score_window_kernel, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_bands, d_scores);
+                                 const uint8_t* d_contigs, const uint16_t* d_bands, int32_t* d_scores, const uint32_t* d_cls, hipStream_t stream) {
+    if (n_pairs) hipLaunchKernelGGL(banded_score_window_kernel, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_bands, d_scores, d_cls);
 }
 
 }  // namespace stitch

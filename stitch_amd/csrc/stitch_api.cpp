@@ -29,19 +29,22 @@
 
 namespace stitch {
 void launch_banded_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
-                          const uint16_t* d_bands, int32_t* d_state, int32_t* d_scores, hipStream_t stream);
+                          const uint16_t* d_bands, int32_t* d_state, int32_t* d_scores, const uint32_t* d_cls, uint32_t my_class, hipStream_t stream);
 uint32_t banded_ring_rows();
 bool launch_banded_scores_lds(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, uint32_t max_m, const BandScoring& sc, const uint8_t* d_reads,
-                              const uint8_t* d_contigs, const uint16_t* d_bands, int32_t* d_scores, hipStream_t stream);
+                              const uint8_t* d_contigs, const uint16_t* d_bands, int32_t* d_scores, const uint32_t* d_cls, hipStream_t stream);
 void launch_full_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_full, uint32_t max_m, const BandScoring& sc, const uint8_t* d_reads,
                         const uint8_t* d_contigs, int32_t* d_scores, hipStream_t stream);
 uint32_t full_score_max_rows();
 bool launch_full_scores_skew16(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_full, uint32_t max_m, uint32_t max_n, const BandScoring& sc,
                                const uint8_t* d_reads, const uint8_t* d_contigs, int32_t* d_scores, hipStream_t stream);
+uint32_t band_device_max_cols();
+void launch_band_draw(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, uint32_t max_n, const BandElem* d_elems, uint32_t w, uint32_t ring_rows,
+                      bool window, uint16_t* d_bands, uint32_t* d_cls, hipStream_t stream);
 bool band_fits_window(const uint16_t* lo, const uint16_t* hi, uint32_t m, uint32_t n);
 bool window_scoring_ok(const BandScoring& sc, uint32_t max_m);
 void launch_banded_scores_window(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads,
-                                 const uint8_t* d_contigs, const uint16_t* d_bands, int32_t* d_scores, hipStream_t stream);
+                                 const uint8_t* d_contigs, const uint16_t* d_bands, int32_t* d_scores, const uint32_t* d_cls, hipStream_t stream);
 struct FillShared {
     const int32_t* S0; const uint32_t* Slen0; const int32_t* Sn0; const uint8_t* SnSet0; const uint8_t* Smove0;
     const uint32_t* lx0; const JumpBase* base0;
@@ -86,7 +89,7 @@ struct Job {                                     // one full jump DP
 // Diagnostic / experiment knobs, read from the environment ONCE when a context is created (never per launch).
 struct Knobs {
     bool fail_first_attempt = false;             // test hook: treat the first attempt of every cooperative launch as timed out
-    bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false, no_regs32 = false, force_regs32 = false, no_pipeline = false, no_fill_overlap = false, prealign_v1 = false;
+    bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false, no_regs32 = false, force_regs32 = false, no_pipeline = false, no_fill_overlap = false, prealign_v1 = false, host_bands = false;
     size_t array_align = 0, job_align = 0;
     std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
@@ -100,6 +103,7 @@ struct Knobs {
         k.no_regs = getenv("STITCH_NO_REGS") != nullptr;             // keep the state-streaming kernel even where the register-resident one applies
         k.no_fill_overlap = getenv("STITCH_NO_FILL_OVERLAP") != nullptr;      // two windows, but a fill starts only when the one before it has ended
         k.no_pipeline = getenv("STITCH_NO_PIPELINE") != nullptr;     // one arena window: a launch is finished before the next fill starts
+        k.host_bands = getenv("STITCH_PREALIGN_HOST_BANDS") != nullptr;     // the pre-alignment's bands drawn and classified on the host (the path of targets beyond the band kernel's LDS)
         k.prealign_v1 = getenv("STITCH_PREALIGN_V1") != nullptr;     // the pre-alignment's first-generation score kernels (A/B runs, tests)
         k.no_regs32 = getenv("STITCH_NO_REGS32") != nullptr;         // keep the generic kernel where the 32-bit register-resident one applies
         k.force_regs32 = getenv("STITCH_FORCE_REGS32") != nullptr;   // (tests) the 32-bit register-resident kernel also where a 16-bit Local-mode kernel applies
@@ -563,7 +567,14 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     const bool quiet = !c.knobs.debug && !c.knobs.profile_dump && !c.knobs.fill_only && c.knobs.dump_dir.empty() && !c.knobs.no_pipeline && !c.knobs.fail_first_attempt;
     const size_t win_align = std::max<size_t>(block_align, 256);
     const bool want_two = quiet && jobs.size() > win_jobs && 2 * align_up(want + (1 << 20), win_align) + win_align <= budget;
-    size_t arena_need = std::min(want_two ? 2 * align_up(want + (1 << 20), win_align) : want + (1 << 20), budget);
+    // Where two full windows do not fit (cfg5: ten 20 kb reads against 200 contigs are 200 GB of traceback) but half the memory still
+    // holds several reads, the launches are made half as large instead and two of them are in flight: the same number of
+    // workgroups on the chip, and fix-up, walk and downloads of one launch beside the fill of the next.
+    size_t max_stride = 0; for (size_t k = 0; k < jobs.size(); ++k) max_stride = std::max(max_stride, lay[k].stride);
+    const size_t per_job_room = sizeof(JobView) + sizeof(WalkArgs) + 512;
+    const bool want_halves = quiet && !want_two && win_jobs >= 4 && jobs.size() >= 4 && want + (1 << 20) > budget / 2 &&
+                             2 * (max_stride + per_job_room) + ((size_t)4 << 20) <= budget / 2 / win_align * win_align;
+    size_t arena_need = std::min(want_two ? 2 * align_up(want + (1 << 20), win_align) : want_halves ? budget : want + (1 << 20), budget);
     if (arena_need > c.arena_bytes) {
         // growing costs seconds (free + allocate: ~5 s for 250 GB), so a context that has to grow takes half as much again
         if (c.arena) arena_need = std::min(budget, arena_need + arena_need / 2);
@@ -589,7 +600,8 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     }
     // (an arena that was large enough already may hold two windows too)
     const size_t half = (c.arena_bytes / 2) / win_align * win_align;
-    const bool pipeline = quiet && jobs.size() > win_jobs && half >= want + (1 << 20);
+    const bool pipeline = quiet && ((jobs.size() > win_jobs && half >= want + (1 << 20)) ||
+                                    (want_halves && half >= 2 * (max_stride + per_job_room) + ((size_t)4 << 20)));
     const size_t win_bytes = pipeline ? half : c.arena_bytes;
     if (c.knobs.debug) fprintf(stderr, "[stitch] %s window(s) of %zu bytes\n", pipeline ? "two" : "one", win_bytes);
     FillShared sh{c.d_S0, c.d_Slen0, c.d_Sn0, c.d_SnSet0, c.d_Smove0, c.d_lx0, c.d_base0};
@@ -1046,6 +1058,11 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
     BandPair* d_fpairs = (BandPair*)p0; p0 += al256(NP * sizeof(BandPair));
     uint32_t* d_fids = (uint32_t*)p0; p0 += al256(NP * 4);
     int32_t* d_fscores = (int32_t*)p0; p0 += al256(NP * 4);
+    uint32_t* d_cls = (uint32_t*)p0; p0 += al256(NP * 4);
+    // the bands: drawn and classified on the device from the backbone's pieces (prealign_band.hip), or, for targets beyond that
+    // kernel's LDS and on request, on the host
+    const bool dev_bands = !c.knobs.prealign_v1 && !c.knobs.host_bands && !c.knobs.banded_global && max_n + 1 <= band_device_max_cols();
+    const bool win_scoring = window_scoring_ok(sc, 65535);
     const size_t call_bytes = (size_t)(p0 - c.pre_buf);
     if (call_bytes + 8192 > c.pre_bytes) return fail(STITCH_ENOMEM, "pre_align: the batch does not fit in the pre-alignment scratch (STITCH_PREALIGN_BYTES)");
     const size_t region_bytes = (c.pre_bytes - call_bytes) / 2 / 256 * 256;
@@ -1059,7 +1076,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         while (k1 < NJ && k1 - k0 < PRE_CHUNK) {
             const size_t m = jobs[k1].y.size();
             size_t need = 0;
-            for (uint32_t a = 0; a < C; ++a) need += al256(4ull * (c.al[a].m + 1)) + al256(12ull * (m + 1)) + 16;
+            for (uint32_t a = 0; a < C; ++a) need += al256(4ull * (c.al[a].m + 1)) + al256(12ull * (m + 1)) + 16 + 64 * sizeof(BandElem);
             if (bytes + need + 4096 > region_bytes) break;
             bytes += need; ++k1;
         }
@@ -1075,7 +1092,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
     const uint64_t per_read = a_off[C];
     {
         size_t most = 0; for (auto& ch : chunks) most = std::max(most, ch.second - ch.first);
-        const size_t want = most * per_read;
+        const size_t want = dev_bands ? 0 : most * per_read;
         if (want > c.pin_bands_elems) {
             for (auto*& b : c.pin_bands) { if (b) { (void)hipHostFree(b); b = nullptr; } }
             c.pin_bands_elems = 0;
@@ -1085,7 +1102,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
     }
     struct Staged {                                   // what the host stage hands to the device stage
         size_t k0 = 0, k1 = 0;
-        const uint16_t* bands = nullptr; size_t band_elems = 0; std::vector<BandPair> pairs;
+        const uint16_t* bands = nullptr; size_t band_elems = 0; std::vector<BandPair> pairs; std::vector<BandElem> elems;      // (elems: the bands' pieces, when the device draws them)
         std::vector<uint32_t> full_ids, win_ids, banded_ids, tall_ids; uint32_t banded_max_m = 0; size_t state_elems = 0;   // ids = pair index in the CALL; win = register-window kernel, banded = LDS-ring kernel, tall = global-state kernel
         double host_ms = 0;
     };
@@ -1096,7 +1113,8 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         std::vector<uint64_t> state_at(nj);
         for (size_t q = 0; q < nj; ++q) { state_at[q] = S.state_elems; S.state_elems += (size_t)C * 3ull * (jobs[k0 + q].y.size() + 1); }
         std::vector<uint8_t> full(np, 0);                     // 1 = full matrix, 2 = a band column taller than the LDS ring, 3 = fits the register window
-        const bool win_ok = !c.knobs.prealign_v1 && !c.knobs.banded_global && window_scoring_ok(sc, 65535);
+        const bool win_ok = !c.knobs.prealign_v1 && !c.knobs.banded_global && win_scoring;
+        std::vector<std::vector<BandElem>> elems_of(dev_bands ? nj : 0);
         const uint32_t ring = banded_ring_rows();
         // seeds, backbone and band of every pair: independent per read, so the reads are dealt to host threads
         {
@@ -1105,7 +1123,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
             std::atomic<bool> failed{false};
             auto work = [&]() {
                 try {
-                std::vector<uint16_t> lo_, hi_; std::vector<std::vector<Seed>> seeds_;
+                std::vector<uint16_t> lo_, hi_; std::vector<std::vector<Seed>> seeds_; std::vector<uint32_t> chain_; std::vector<BandElem> el_;
                 for (;;) {
                     const size_t q = next.fetch_add(1); if (q >= nj) break;
                     const Job& jb = jobs[k0 + q];
@@ -1115,11 +1133,18 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
                         const Aligner& A = c.al[a];
                         BandPair& P = S.pairs[q * C + a];
                         P.m = m; P.n = A.m; P.q_off = q_at[k0 + q]; P.t_off = A.seqoff; P.band_off = 0; P.state_off = 0;
-                        const bool is_full = make_band(seeds_[a], m, A.m, (uint32_t)c.opts.kmer_size, (uint32_t)c.opts.band_width,
-                                                       c.opts.match_score, c.opts.gap_open, c.opts.gap_extend, lo_, hi_);
+                        P.elem_off = 0; P.n_elem = 0;
+                        const bool is_full = backbone_chain(seeds_[a], (uint32_t)c.opts.kmer_size, c.opts.match_score, c.opts.gap_open, c.opts.gap_extend, chain_);
                         if (is_full && m <= full_score_max_rows()) { full[q * C + a] = 1; continue; }                   // full-matrix kernels: no band needed
                         P.band_off = q * per_read + a_off[a];
                         P.state_off = state_at[q] + (uint64_t)a * 3ull * (m + 1);
+                        if (dev_bands) {                                                // the backbone's pieces; the device draws the band and picks the kernel
+                            band_elements(seeds_[a], chain_, m, A.m, (uint32_t)c.opts.kmer_size, el_);      // (none: the full matrix of a read too long for the full-matrix kernels)
+                            P.elem_off = (uint32_t)elems_of[q].size(); P.n_elem = (uint32_t)el_.size();
+                            elems_of[q].insert(elems_of[q].end(), el_.begin(), el_.end());
+                            continue;
+                        }
+                        rasterise_band(seeds_[a], chain_, m, A.m, (uint32_t)c.opts.kmer_size, (uint32_t)c.opts.band_width, lo_, hi_);
                         if (win_ok && band_fits_window(lo_.data(), hi_.data(), m, A.m)) full[q * C + a] = 3;
                         else for (uint32_t col = 0; col <= A.m; ++col) if (hi_[col] > lo_[col] && (uint32_t)(hi_[col] - lo_[col]) > ring) { full[q * C + a] = 2; break; }
                         memcpy(bands + P.band_off, lo_.data(), sizeof(uint16_t) * (A.m + 1));
@@ -1133,6 +1158,13 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
             work();
             for (auto& th : J.pool) th.join();
             if (failed.load()) throw std::bad_alloc();
+        }
+        if (dev_bands) {
+            for (size_t q = 0; q < nj; ++q) {
+                const uint32_t at = (uint32_t)S.elems.size();
+                for (uint32_t a = 0; a < C; ++a) S.pairs[q * C + a].elem_off += at;
+                S.elems.insert(S.elems.end(), elems_of[q].begin(), elems_of[q].end());
+            }
         }
         const uint32_t g0 = (uint32_t)(k0 * C);
         for (size_t k = 0; k < np; ++k) {
@@ -1179,23 +1211,32 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         uint32_t* d_banded = (uint32_t*)p; p += al256(S.banded_ids.size() * 4);
         uint32_t* d_tall = (uint32_t*)p; p += al256(S.tall_ids.size() * 4);
         uint32_t* d_win = (uint32_t*)p; p += al256(S.win_ids.size() * 4);
+        BandElem* d_elems = (BandElem*)p; p += al256(S.elems.size() * sizeof(BandElem));
         int32_t* d_state = (int32_t*)p; p += al256(S.state_elems * 4);
         if (p > p_end) return fail(STITCH_EINTERNAL, "pre-alignment scratch overflow");
         // the uploads (128 MB of band ranges per 64 reads at cfg3) go on a stream of their own, beside the kernels of the chunk before
         hipStream_t up = c.stream3;
-        HIP_TRY(hipMemcpyAsync(d_bands, S.bands, S.band_elems * 2, hipMemcpyHostToDevice, up));
+        if (!dev_bands) HIP_TRY(hipMemcpyAsync(d_bands, S.bands, S.band_elems * 2, hipMemcpyHostToDevice, up));
+        else if (!S.elems.empty()) HIP_TRY(hipMemcpyAsync(d_elems, S.elems.data(), S.elems.size() * sizeof(BandElem), hipMemcpyHostToDevice, up));
         HIP_TRY(hipMemcpyAsync(d_pairs + g0, S.pairs.data(), np * sizeof(BandPair), hipMemcpyHostToDevice, up));
         if (!S.banded_ids.empty()) HIP_TRY(hipMemcpyAsync(d_banded, S.banded_ids.data(), S.banded_ids.size() * 4, hipMemcpyHostToDevice, up));
         if (!S.tall_ids.empty()) HIP_TRY(hipMemcpyAsync(d_tall, S.tall_ids.data(), S.tall_ids.size() * 4, hipMemcpyHostToDevice, up));
         if (!S.win_ids.empty()) HIP_TRY(hipMemcpyAsync(d_win, S.win_ids.data(), S.win_ids.size() * 4, hipMemcpyHostToDevice, up));
         HIP_TRY(hipEventRecord(c.evu[i & 1], up));
         HIP_TRY(hipStreamWaitEvent(c.stream2, c.evu[i & 1], 0));
-        if (!S.win_ids.empty()) {
-            launch_banded_scores_window(d_pairs, d_win, (uint32_t)S.win_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream2);
+        if (dev_bands) {          // every pair with a band is in `banded_ids`; the band kernel draws the band and names the score kernel, each of which skips the others' pairs
+            const uint32_t nb = (uint32_t)S.banded_ids.size();
+            launch_band_draw(d_pairs, d_banded, nb, max_n, d_elems, (uint32_t)c.opts.band_width, banded_ring_rows(), win_scoring, d_bands, d_cls, c.stream2);
+            if (win_scoring) launch_banded_scores_window(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_scores, d_cls, c.stream2);
+            if (!launch_banded_scores_lds(d_pairs, d_banded, nb, S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, d_cls, c.stream2))
+                launch_banded_scores(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, d_cls, BAND_CLASS_RING, c.stream2);
+            launch_banded_scores(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, d_cls, BAND_CLASS_TALL, c.stream2);
+        } else {
+            if (!S.win_ids.empty()) launch_banded_scores_window(d_pairs, d_win, (uint32_t)S.win_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_scores, nullptr, c.stream2);
+            if (c.knobs.banded_global || !launch_banded_scores_lds(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, nullptr, c.stream2))
+                launch_banded_scores(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, nullptr, 0, c.stream2);
+            launch_banded_scores(d_pairs, d_tall, (uint32_t)S.tall_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, nullptr, 0, c.stream2);
         }
-        if (c.knobs.banded_global || !launch_banded_scores_lds(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, c.stream2))
-            launch_banded_scores(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream2);
-        launch_banded_scores(d_pairs, d_tall, (uint32_t)S.tall_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, c.stream2);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.evc[i & 1], c.stream2));
         for (uint32_t g : S.full_ids) { f_gid.push_back(g); f_pairs.push_back(S.pairs[g - g0]); }
@@ -1504,6 +1545,36 @@ int stitch_prealign_band(const uint8_t* read, uint32_t read_len, const uint8_t* 
     find_seeds(ix, target, st, read, read_len, seeds);
     const bool full = make_band(seeds[0], read_len, target_len, k, w, match, gap_open, gap_extend, l, h);
     memcpy(lo, l.data(), 2ull * (target_len + 1)); memcpy(hi, h.data(), 2ull * (target_len + 1));
+    return full ? 1 : 0;
+}
+
+int stitch_prealign_band_device(int device, const uint8_t* read, uint32_t read_len, const uint8_t* target, uint32_t target_len, uint32_t k, uint32_t w,
+                                int32_t match, int32_t gap_open, int32_t gap_extend, uint16_t* lo, uint16_t* hi, uint32_t* kernel_class) {
+    if (!read || !target || !lo || !hi) return fail(STITCH_EINVAL, "null argument");
+    if (read_len > 65534) return fail(STITCH_EINVAL, "pre_align: reads longer than 65534 bases are not supported");
+    if (target_len + 1 > band_device_max_cols()) return fail(STITCH_EINVAL, "the device draws bands of up to 8191 columns");
+    std::vector<Strand> st{Strand{0, target_len}};
+    const KmerIndex ix = build_kmer_index(target, st, k);
+    std::vector<std::vector<Seed>> seeds; std::vector<uint32_t> chain; std::vector<BandElem> el;
+    find_seeds(ix, target, st, read, read_len, seeds);
+    const bool full = backbone_chain(seeds[0], k, match, gap_open, gap_extend, chain);
+    band_elements(seeds[0], chain, read_len, target_len, k, el);
+    HIP_TRY(hipSetDevice(device));
+    BandPair P{}; P.m = read_len; P.n = target_len; P.band_off = 0; P.elem_off = 0; P.n_elem = (uint32_t)el.size();
+    const uint32_t zero = 0;
+    struct Bufs { BandPair* p = nullptr; uint32_t* w = nullptr; BandElem* e = nullptr; uint16_t* b = nullptr; uint32_t* c = nullptr;
+                  ~Bufs() { (void)hipFree(p); (void)hipFree(w); (void)hipFree(e); (void)hipFree(b); (void)hipFree(c); } } B;
+    HIP_TRY(hipMalloc((void**)&B.p, sizeof(P))); HIP_TRY(hipMalloc((void**)&B.w, 4)); HIP_TRY(hipMalloc((void**)&B.e, std::max<size_t>(1, el.size()) * sizeof(BandElem)));
+    HIP_TRY(hipMalloc((void**)&B.b, 4ull * (target_len + 1))); HIP_TRY(hipMalloc((void**)&B.c, 4));
+    HIP_TRY(hipMemcpy(B.p, &P, sizeof(P), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(B.w, &zero, 4, hipMemcpyHostToDevice));
+    if (!el.empty()) HIP_TRY(hipMemcpy(B.e, el.data(), el.size() * sizeof(BandElem), hipMemcpyHostToDevice));
+    launch_band_draw(B.p, B.w, 1, target_len, B.e, w, banded_ring_rows(), true, B.b, B.c, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(lo, B.b, 2ull * (target_len + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hi, B.b + (target_len + 1), 2ull * (target_len + 1), hipMemcpyDeviceToHost));
+    uint32_t cls = 0; HIP_TRY(hipMemcpy(&cls, B.c, 4, hipMemcpyDeviceToHost));
+    if (kernel_class) *kernel_class = cls;
     return full ? 1 : 0;
 }
 

@@ -69,7 +69,7 @@ def main():
         n_reads = args.reads or 36
         reads = synth.make_reads(db, n_reads, 20000, 47, sub=0.01, ins=0.005, dele=0.005, circular=True)
         opts = dict(circular=True, suboptimal=True)
-        batch = args.batch or 10                   # one launch: 200 contigs = 50 workgroups per read, ten reads fill the 512 workgroup slots (and 200 GB of traceback)
+        batch = args.batch or 36                   # 200 contigs = 50 workgroups per read: six reads per launch (120 GB of traceback), two launches in flight
     targets = [stitch_amd.TargetSeq(n, s) for n, s in db]
     al = stitch_amd.Builder(**opts).build_aligners(targets)
 

@@ -138,6 +138,92 @@ def test_product_band_equals_oracle_band(seed):
     assert np.array_equal(p[1], o[1]) and np.array_equal(p[2], o[2])
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_product_band_with_bytes_other_than_acgt(seed):
+    """k-mers holding N (or any other byte) match by their bytes: the 2-bit table of the four-letter k-mers and the byte-hash index
+    beside it must together give the oracle's seeds; k = 33 has no table at all"""
+    import numpy as np
+    rng = random.Random(7000 + seed)
+    alpha = "ACGTN" if seed % 2 else "ACGTNRY"
+    y = "".join(rng.choice(alpha if rng.random() < 0.08 else "ACGT") for _ in range(rng.randint(80, 700)))
+    a = rng.randint(0, len(y) // 2)
+    x = rnd(rng, rng.randint(0, 60)) + mutate(rng, y[a:a + rng.randint(40, 300)], 0.03, 0.01, 0.01) + "".join(rng.choice(alpha) for _ in range(rng.randint(0, 50)))
+    k = rng.choice([3, 5, 8, 12, 33]) if seed % 5 else 33
+    p, o = _bands(x, y, k, rng.choice([2, 20]))
+    assert (not p[0]) or o[0]
+    assert np.array_equal(p[1], o[1]) and np.array_equal(p[2], o[2])
+
+
+def _device_band(x, y, k, w, match=1, go=-6, ge=-2):
+    import numpy as np
+    from stitch_amd import api
+    xb = (C.c_uint8 * max(1, len(x))).from_buffer_copy((x or "\0").encode()); yb = (C.c_uint8 * max(1, len(y))).from_buffer_copy((y or "\0").encode())
+    lo = np.zeros(len(y) + 1, dtype=np.uint16); hi = np.zeros(len(y) + 1, dtype=np.uint16)
+    cls = C.c_uint32(99)
+    full = api.lib().stitch_prealign_band_device(0, xb, len(x), yb, len(y), k, w, match, go, ge, lo.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                 hi.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(cls))
+    assert full >= 0, api.lib().stitch_last_error()
+    return full, lo.astype(np.int64), hi.astype(np.int64), cls.value
+
+
+def _kernel_class(lo, hi, m):
+    """which score kernel a band goes to (prealign_window.hip band_fits_window, prealign_kernel.hip BAND_RING), restated"""
+    prev, window = 0, True
+    for c in range(1, len(lo)):
+        r0, r1 = max(int(lo[c]), 1), min(int(hi[c]), m + 1)
+        if r0 >= r1:
+            continue
+        if r0 < prev or r1 - ((r0 - 1) & ~3) > 256:
+            window = False
+        prev = max(prev, r0)
+    if window:
+        return 3
+    return 2 if any(h > l and h - l > 512 for l, h in zip(lo, hi)) else 0
+
+
+@pytest.mark.gpu
+def test_device_band_equals_oracle_band():
+    """the band as the DEVICE draws it from the backbone's pieces (prealign_band.hip: what production uses) against the oracle's,
+    column by column, on the inputs of the two host tests above and on long gaps; and the score kernel it names"""
+    import numpy as np
+    cases = []
+    for seed in range(240):
+        rng = random.Random(300 + seed)
+        y = rnd(rng, rng.randint(50, 900))
+        kind = seed % 4
+        if kind == 0:
+            x = rnd(rng, rng.randint(20, 600))
+        elif kind == 1:
+            a = rng.randint(0, len(y) // 2); x = rnd(rng, rng.randint(0, 80)) + mutate(rng, y[a:a + rng.randint(40, 400)], 0.05, 0.03, 0.03) + rnd(rng, rng.randint(0, 80))
+        elif kind == 2:
+            a = rng.randint(0, len(y) // 3); b = rng.randint(len(y) // 2, len(y) - 10)
+            x = y[a:a + 60] + rnd(rng, rng.randint(0, 200)) + y[b:b + 60] + y[a:a + 40]
+        else:
+            unit = rnd(rng, rng.randint(3, 9)); y = (unit * 80)[:len(y)] if rng.random() < 0.5 else y
+            x = (unit * 40)[:rng.randint(30, 250)]
+        k = rng.choice([4, 6, 8, 12]); w = rng.choice([0, 3, 20, 50])
+        go, ge = rng.choice([(-6, -2), (0, -1), (-3, -3)])
+        cases.append((x, y, k, w, rng.choice([1, 2]), go, ge))
+    rng = random.Random(99)
+    t = rnd(rng, 4000)
+    for gap_x, gap_y in ((0, 600), (600, 0), (400, 150), (3, 500), (500, 3), (150, 0), (0, 150), (1, 1), (2, 0), (0, 2), (64, 65)):      # long and lopsided gaps between two exact stretches (the backbone keeps both: 1500 matches pay for the gap)
+        x = t[100:1600] + rnd(rng, gap_x) + t[1600 + gap_y:3100 + gap_y]
+        for w in (0, 7, 50):
+            cases.append((x, t, 12, w, 1, -6, -2))
+    cases.append((rnd(rng, 3000) + t[:300], t, 12, 50, 1, -6, -2))              # the band starts 3000 rows down
+    cases.append((t[3700:], t, 12, 50, 1, -6, -2))                               # ... and 3700 columns in
+    n_window = n_other = 0
+    for x, y, k, w, match, go, ge in cases:
+        full, lo, hi, cls = _device_band(x, y, k, w, match, go, ge)
+        _, o = _bands(x, y, k, w, match=match, go=go, ge=ge)
+        assert (not full) or o[0]
+        assert np.array_equal(lo, o[1]) and np.array_equal(hi, o[2]), (len(x), len(y), k, w)
+        if not full:
+            assert cls == _kernel_class(lo, hi, len(x)), (len(x), len(y), k, w, cls)
+            n_window += cls == 3; n_other += cls != 3
+    assert n_window > 100 and n_other > 5
+
+
 # ---- product vs oracle ---------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("opts", [dict(), dict(double_strand=True), dict(pre_align_subset_contigs=False, double_strand=True),
