@@ -1,5 +1,5 @@
 """GPU fuzz of the Local kernel's multi-tile paths (and the pre-alignment filter) against the oracle.  Not collected by pytest:
-run `FUZZ_SECONDS=600 FUZZ_SEED=1000 python tests/gpu_fuzz.py` on a GPU box (round 1: 9971 cases, all equal; FUZZ_MODES=1 also draws the non-local modes)."""
+run `FUZZ_SECONDS=600 FUZZ_SEED=1000 python tests/gpu_fuzz.py` on a GPU box (round 1: 9971 cases, all equal; FUZZ_MODES=1 also draws the non-local modes, FUZZ_PREALIGN=1 sends every case through the pre-alignment filter)."""
 import os, random, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import stitch_amd
@@ -20,6 +20,9 @@ while time.time() < t_end:
                     default_jump_score=rng.choice([-10, -5, -1]))
     if os.environ.get("FUZZ_MODES") and rng.random() < 0.5:       # the generic int32 kernel: the other clipping modes
         opts.update(mode=rng.choice(["query-local", "target-local", "global"]))
+    elif os.environ.get("FUZZ_PREALIGN"):                             # every case through the filter: drawn bands, register-window / LDS-ring / full-matrix kernels
+        opts.update(pre_align=True, pre_align_min_score=rng.choice([1, 20, 60, 80]), kmer_size=rng.choice([6, 8, 11, 13]), band_width=rng.choice([0, 5, 30, 50, 62, 70]),
+                    pre_align_subset_contigs=rng.random() < 0.7)
     elif rng.random() < 0.2:
         opts.update(pre_align=True, pre_align_min_score=rng.choice([20, 60]), kmer_size=rng.choice([8, 11]), band_width=rng.choice([5, 30]))
     nreads = rng.choice([1, 2, 5, 30])
