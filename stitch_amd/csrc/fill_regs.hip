@@ -242,24 +242,30 @@ __device__ __forceinline__ void group_records(Recs& R, const uint32_t g4, const 
 
 // NQ = granule registers per lane: 1 for up to 64 active contigs, 4 for up to 256
 template <int NQ, bool CIRC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS_WAVES_PER_EU, STITCH_REGS_WAVES_PER_EU))) void fill_regs_kernel(const JobView* __restrict__ jobs, FillShared sh, uint32_t G) {
-    // (the quotient comes out of vector arithmetic: tell the compiler it is uniform, so that everything read through V is scalar)
-    const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / G));
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS_WAVES_PER_EU, STITCH_REGS_WAVES_PER_EU))) void fill_regs_kernel(const JobView* __restrict__ jobs, FillShared sh, const uint2* __restrict__ wave_map, uint32_t n_waves) {
+    // The launch's waves are dealt to the reads' contigs DENSELY: wave w of the grid is entry w of `wave_map` = {read of the launch,
+    // active contig of that read}.  A team (the waves of one read) needs nothing of a workgroup - no barrier, no shared LDS, the
+    // exchange goes through memory - so its waves may sit in any workgroups; the host keeps the launch within the wave slots of the
+    // chip, so all of them are resident.  (Before: whole workgroups per read, whose spare waves idled: a read cut down to two contigs
+    // by the pre-alignment filter used half a workgroup, 50 contigs 52 waves.)
+    const uint32_t wv = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    if (wv >= n_waves) return;
+    const uint2 wm = wave_map[wv];
+    // (tell the compiler these are uniform, so that everything read through V is scalar)
+    const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm.x);
     const JobView& V = jobs[job];
-    const uint32_t part = blockIdx.x - job * G;
 #ifdef STITCH_EXP_PRIO
     if (job & 1u) __builtin_amdgcn_s_setprio(2);       // experiment: every other read's team has priority on the SIMDs it shares
 #endif
     const DpParams P = V.P;
     const uint32_t n = V.n, nact = V.nact, Rtot = V.Rtot, C = V.C;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform, provably)
-    const uint32_t RW = blockDim.x >> 6;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     uint8_t* const s_wave = s_dyn + (size_t)wave * LDS_PER_WAVE;
 
-    // ---- this wave's contig: active contig number (part * RW + wave) ------------------------------------------------------------
-    const uint32_t kmine = (uint32_t)__builtin_amdgcn_readfirstlane((int)(part * RW + (uint32_t)wave));      // (wave-uniform, provably)
-    if (kmine >= nact) return;                        // (more waves than contigs: nobody waits for this wave)
+    // ---- this wave's contig: active contig number ------------------------------------------------------------------------------------
+    const uint32_t kmine = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm.y);
+    if (kmine >= nact) return;
     const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)V.act[kmine]);
     ContigDesc cd = V.cd[c];
     cd.m = (uint32_t)__builtin_amdgcn_readfirstlane((int)cd.m); cd.roff = (uint32_t)__builtin_amdgcn_readfirstlane((int)cd.roff);
@@ -796,10 +802,10 @@ int fill_regs_workgroups_per_cu(uint32_t waves) {
     return least;
 }
 // max_nact: the largest number of active contigs of any job of the launch; circular: opts.circular
-void launch_fill_regs(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream) {
-    const dim3 grid(n_jobs * G), block(waves * 64); const size_t lds = (size_t)waves * LDS_PER_WAVE;
-    if (max_nact <= 64) { if (circular) hipLaunchKernelGGL((fill_regs_kernel<1, true>), grid, block, lds, stream, d_jobs, sh, G); else hipLaunchKernelGGL((fill_regs_kernel<1, false>), grid, block, lds, stream, d_jobs, sh, G); }
-    else { if (circular) hipLaunchKernelGGL((fill_regs_kernel<4, true>), grid, block, lds, stream, d_jobs, sh, G); else hipLaunchKernelGGL((fill_regs_kernel<4, false>), grid, block, lds, stream, d_jobs, sh, G); }
+void launch_fill_regs(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream) {
+    const dim3 grid((n_waves + waves - 1) / waves), block(waves * 64); const size_t lds = (size_t)waves * LDS_PER_WAVE;
+    if (max_nact <= 64) { if (circular) hipLaunchKernelGGL((fill_regs_kernel<1, true>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); else hipLaunchKernelGGL((fill_regs_kernel<1, false>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); }
+    else { if (circular) hipLaunchKernelGGL((fill_regs_kernel<4, true>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); else hipLaunchKernelGGL((fill_regs_kernel<4, false>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); }
 }
 
 }  // namespace stitch

@@ -55,7 +55,7 @@ constexpr size_t PIN_BYTES = (size_t)64 << 20;   // pinned staging buffer for re
 constexpr uint32_t TILE_ROWS = 512;   // 64 lanes x 8 rows (Local-mode kernel; the generic one uses 256): contig row blocks are padded to this
 void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, uint32_t slots_cap, const FillShared& sh, hipStream_t stream);
 uint32_t fill_local16_max_slots();
-void launch_fill_regs(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
+void launch_fill_regs(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
 uint32_t fill_regs_rows_per_wave();
 int fill_regs_workgroups_per_cu(uint32_t waves);
 void launch_fill_regs32(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
@@ -525,7 +525,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     // 170 ms after the fastest in a 585 ms launch, the same slots every time, whatever read or CUs they get); blocks at
     // multiples of 1 GiB: 505 ms, 128 or 512 MiB: 541, 16 MiB: 695, 1 GiB + 256 KiB: 594.  So: the largest power of two
     // (<= 1 GiB, <= the job size) that still lets the launch window fit the memory.
-    size_t want = 0, block_align = 256, win_jobs = jobs.size();
+    size_t want = 0, block_align = 256, win_jobs = jobs.size(), regs_wave_cap = 0;
     for (size_t a = (size_t)1 << 30; a >= 256; a >>= 1) {
         if (a > max_job && a > 256) continue;
         if (c.knobs.job_align) a = std::max<size_t>(256, c.knobs.job_align);      // (experiments)
@@ -548,7 +548,21 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         uint32_t rg_min = 0xFFFFFFFFu;
         if (all_fast) for (const Job& jb : jobs) rg_min = std::min(rg_min, regs_plan(c, jb));
         size_t win = (all_fast && gd_min > 1) ? std::min<size_t>(jobs.size(), (size_t)std::max(1, c.n_cus) / gd_min) : jobs.size();
-        if (all_fast && rg_min > 1 && rg_min != 0xFFFFFFFFu) win = std::min<size_t>(jobs.size(), std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs_wg_per_cu / rg_min));
+        if (all_fast && rg_min > 0 && rg_min != 0xFFFFFFFFu && !c.knobs.force_regs32) {
+            // the register kernel: a launch holds the reads whose contigs fill the chip's wave slots - or an equal share of the batch
+            // where that leaves a remainder: a launch lasts its reads' columns however few they are, and two launches of half the
+            // chip each run side by side (two windows, two streams) in the time one of them takes alone
+            const size_t slots = (size_t)c.n_cus * (size_t)c.regs_wg_per_cu * REGS_WAVES;
+            size_t W = 0, act_max = 1; for (const Job& jb : jobs) { W += jb.act.size(); act_max = std::max(act_max, jb.act.size()); }
+            regs_wave_cap = slots;
+            if (W > slots) { const size_t nl = (W + slots - 1) / slots; regs_wave_cap = std::min(slots, (W + nl - 1) / nl + act_max); }
+            size_t most = 1, cur_jobs = 0, cur_waves = 0;
+            for (const Job& jb : jobs) {
+                if (cur_jobs && cur_waves + jb.act.size() > regs_wave_cap) { cur_jobs = 0; cur_waves = 0; }
+                ++cur_jobs; cur_waves += jb.act.size(); most = std::max(most, cur_jobs);
+            }
+            win = most;
+        }
         if (!all_fast || c.knobs.force_regs32) {      // (the 32-bit register-resident kernel: one workgroup per CU, all workgroups of a launch resident)
             uint32_t r32_min = 0xFFFFFFFFu;
             for (const Job& jb : jobs) r32_min = std::min(r32_min, regs32_plan(c, jb));
@@ -557,8 +571,8 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         win_jobs = win;
         size_t cur = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
-            cur += lay[k].stride + sizeof(JobView) + sizeof(WalkArgs) + 512;
-            if (k >= win) cur -= lay[k - win].stride + sizeof(JobView) + sizeof(WalkArgs) + 512;
+            cur += lay[k].stride + sizeof(JobView) + sizeof(WalkArgs) + 512 + 8ull * c.C;
+            if (k >= win) cur -= lay[k - win].stride + sizeof(JobView) + sizeof(WalkArgs) + 512 + 8ull * c.C;
             want = std::max(want, cur);
         }
         want += (size_t)2 << 20;
@@ -574,7 +588,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     // holds several reads, the launches are made half as large instead and two of them are in flight: the same number of
     // workgroups on the chip, and fix-up, walk and downloads of one launch beside the fill of the next.
     size_t max_stride = 0; for (size_t k = 0; k < jobs.size(); ++k) max_stride = std::max(max_stride, lay[k].stride);
-    const size_t per_job_room = sizeof(JobView) + sizeof(WalkArgs) + 512;
+    const size_t per_job_room = sizeof(JobView) + sizeof(WalkArgs) + 512 + 8ull * c.C;
     const bool want_halves = quiet && !want_two && win_jobs >= 4 && jobs.size() >= 4 && want + (1 << 20) > budget / 2 &&
                              2 * (max_stride + per_job_room) + ((size_t)4 << 20) <= budget / 2 / win_align * win_align;
     size_t arena_need = std::min(want_two ? 2 * align_up(want + (1 << 20), win_align) : want_halves ? budget : want + (1 << 20), budget);
@@ -649,7 +663,11 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         // every workgroup of a team resident at once: a launch holds no more teams than the chip does - unless a team is ONE workgroup, whose
         // waves are together by construction (reads cut down to a few contigs by the filter: a fill launch lasts its reads' columns
         // whatever their number, so the more the better)
-        if (regs_G > 1) max_jobs = std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs_wg_per_cu / regs_G);
+        // fill_regs.hip deals the launch's waves to the reads' contigs densely (a team's waves sit in any workgroups): the launch holds
+        // what the chip's wave slots hold
+        const size_t regs_wave_slots = regs_wave_cap ? regs_wave_cap : (size_t)c.n_cus * (size_t)std::max(c.regs_wg_per_cu, 0) * REGS_WAVES;
+        size_t regs_waves_used = 0;
+        if (regs_G) max_jobs = 4096;
         else if (regs32_G > 1) max_jobs = std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs32_wg_per_cu / regs32_G);
         else if (fast) {
             uint32_t tiles = 0; for (uint32_t a : jobs[k0].act) tiles += (c.al[a].m + 255) / 256;
@@ -665,9 +683,11 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             if (std::max(g_min, g_des) == 1) max_jobs = 4096;
             if (c.knobs.wg_per_read) max_jobs = std::max<size_t>(1, (size_t)c.n_cus / std::max(g_min, (uint32_t)c.knobs.wg_per_read));
         }
-        const size_t per_job = sizeof(JobView) + sizeof(WalkArgs) + 512;     // the launch's job table, after the jobs' own buffers
+        const size_t per_job = sizeof(JobView) + sizeof(WalkArgs) + 512 + 8ull * c.C;     // the launch's job table (and wave map), after the jobs' own buffers
         while (k1 < jobs.size() && used + lay[k1].stride + per_job + view_room <= win_bytes && (k1 - k0) < max_jobs &&
-               (k1 == k0 || (regs32_G ? regs32_plan(c, jobs[k1]) == regs32_G : (regs_plan(c, jobs[k1]) == regs_G || !fast)))) {
+               (k1 == k0 || (regs32_G ? regs32_plan(c, jobs[k1]) == regs32_G : regs_G ? regs_plan(c, jobs[k1]) > 0 : (regs_plan(c, jobs[k1]) == 0 || !fast))) &&
+               (!regs_G || k1 == k0 || regs_waves_used + lay[k1].nact <= regs_wave_slots)) {
+            if (regs_G) regs_waves_used += lay[k1].nact;
             if (fast && !regs_G && !regs32_G && k1 > k0) {
                 // a later job may need MORE workgroups than the first (shorter read, more contigs): all workgroups of the launch
                 // must still be resident at once
@@ -739,8 +759,12 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         uint8_t* tail = c.arena + win_base + align_up(o, 256);
         JobView* d_views = (JobView*)tail; tail += align_up(sizeof(JobView) * nj, 256);
         WalkArgs* d_wargs = (WalkArgs*)tail; tail += align_up(sizeof(WalkArgs) * nj, 256);
+        std::vector<uint2> wave_map;                     // fill_regs.hip: wave of the grid -> (read of the launch, active contig)
+        if (regs_G) for (uint32_t q = 0; q < nj; ++q) for (uint32_t k = 0; k < lay[k0 + q].nact; ++k) wave_map.push_back(make_uint2(q, k));
+        uint2* d_wave_map = (uint2*)tail; tail += align_up(sizeof(uint2) * wave_map.size(), 256);
         if ((size_t)(tail - c.arena) > win_base + win_bytes) return fail(STITCH_EINTERNAL, "arena overflow");
         Ln.d_views = d_views; Ln.d_wargs = d_wargs;
+        if (!wave_map.empty()) HIP_TRY(hipMemcpyAsync(d_wave_map, wave_map.data(), sizeof(uint2) * wave_map.size(), hipMemcpyHostToDevice, sB));
         HIP_TRY(hipMemcpyAsync(d_views, views.data(), sizeof(JobView) * nj, hipMemcpyHostToDevice, sB));
         HIP_TRY(hipMemcpyAsync(d_wargs, wargs.data(), sizeof(WalkArgs) * nj, hipMemcpyHostToDevice, sB));
         HIP_TRY(hipStreamSynchronize(sB));              // (the staging buffer is free again; with two windows the fill before this one is still running on sA)
@@ -795,7 +819,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         const uint32_t kind = regs_G ? 2u : regs32_G ? 3u : fast ? 1u : 0u;
         Ln.G = G; Ln.kind = kind; Ln.waves = waves; Ln.slots_cap = slots_cap; Ln.g_min = g_min;
         if (kind == 3u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs32(d_views, nj, G, mx, c.opts.circular != 0, sh, sA); }
-        else if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, nj, G, REGS_WAVES, mx, c.opts.circular != 0, sh, sA); }
+        else if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, d_wave_map, (uint32_t)wave_map.size(), REGS_WAVES, mx, c.opts.circular != 0, sh, sA); }
         else if (kind == 1u) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, sA);
         else launch_fill(d_views, nj, waves, sh, sA);
         HIP_TRY(hipGetLastError());
