@@ -231,19 +231,22 @@ template <int I, typename F> __device__ __forceinline__ void for_groups_down(F&&
 
 // NQ = granule registers per lane: 1 for up to 64 active contigs, 4 for up to 256
 template <int NQ, bool CIRC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fill_regs32_kernel(const JobView* __restrict__ jobs, FillShared sh, uint32_t G) {
-    const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / G));
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fill_regs32_kernel(const JobView* __restrict__ jobs, FillShared sh, const uint2* __restrict__ wave_map, uint32_t n_waves) {
+    // the launch's waves are dealt densely to the reads' contigs: wave w of the grid = entry w of `wave_map` = {read of the launch,
+    // active contig} (fill_regs.hip; a team needs nothing of a workgroup)
+    const uint32_t wv = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    if (wv >= n_waves) return;
+    const uint2 wm = wave_map[wv];
+    const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm.x);
     const JobView& V = jobs[job];
-    const uint32_t part = blockIdx.x - job * G;
     const DpParams P = V.P;
     const uint32_t n = V.n, nact = V.nact, Rtot = V.Rtot, C = V.C;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t RW = blockDim.x >> 6;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn32[];
     uint8_t* const s_wave = s_dyn32 + (size_t)wave * LDS32_PER_WAVE;
     const bool xf = P.xclip_prefix == 0, yf = P.yclip_prefix == 0;      // (the four penalties go in pairs: aligners/mod.rs:123-131)
 
-    const uint32_t kmine = (uint32_t)__builtin_amdgcn_readfirstlane((int)(part * RW + (uint32_t)wave));
+    const uint32_t kmine = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm.y);
     if (kmine >= nact) return;
     const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)V.act[kmine]);
     ContigDesc cd = V.cd[c];
@@ -687,10 +690,10 @@ int fill_regs32_workgroups_per_cu() {
     }
     return least;
 }
-void launch_fill_regs32(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream) {
-    const dim3 grid(n_jobs * G), block(256); const size_t lds = (size_t)4 * LDS32_PER_WAVE;
-    if (max_nact <= 64) { if (circular) hipLaunchKernelGGL((fill_regs32_kernel<1, true>), grid, block, lds, stream, d_jobs, sh, G); else hipLaunchKernelGGL((fill_regs32_kernel<1, false>), grid, block, lds, stream, d_jobs, sh, G); }
-    else { if (circular) hipLaunchKernelGGL((fill_regs32_kernel<4, true>), grid, block, lds, stream, d_jobs, sh, G); else hipLaunchKernelGGL((fill_regs32_kernel<4, false>), grid, block, lds, stream, d_jobs, sh, G); }
+void launch_fill_regs32(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream) {
+    const dim3 grid((n_waves + 3) / 4), block(256); const size_t lds = (size_t)4 * LDS32_PER_WAVE;
+    if (max_nact <= 64) { if (circular) hipLaunchKernelGGL((fill_regs32_kernel<1, true>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); else hipLaunchKernelGGL((fill_regs32_kernel<1, false>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); }
+    else { if (circular) hipLaunchKernelGGL((fill_regs32_kernel<4, true>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); else hipLaunchKernelGGL((fill_regs32_kernel<4, false>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); }
 }
 
 }  // namespace stitch

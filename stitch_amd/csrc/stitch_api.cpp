@@ -58,7 +58,7 @@ uint32_t fill_local16_max_slots();
 void launch_fill_regs(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
 uint32_t fill_regs_rows_per_wave();
 int fill_regs_workgroups_per_cu(uint32_t waves);
-void launch_fill_regs32(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
+void launch_fill_regs32(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
 uint32_t fill_regs32_rows_per_wave();
 int fill_regs32_workgroups_per_cu();
 }  // namespace stitch
@@ -566,7 +566,10 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         if (!all_fast || c.knobs.force_regs32) {      // (the 32-bit register-resident kernel: one workgroup per CU, all workgroups of a launch resident)
             uint32_t r32_min = 0xFFFFFFFFu;
             for (const Job& jb : jobs) r32_min = std::min(r32_min, regs32_plan(c, jb));
-            if (r32_min > 1 && r32_min != 0xFFFFFFFFu) win = std::min<size_t>(jobs.size(), std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs32_wg_per_cu / r32_min));
+            if (r32_min > 0 && r32_min != 0xFFFFFFFFu) {      // (as many reads as its wave slots hold: the waves are dealt densely there too)
+                size_t act_min = ~(size_t)0; for (const Job& jb : jobs) act_min = std::min(act_min, jb.act.size());
+                win = std::min<size_t>(jobs.size(), std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs32_wg_per_cu * REGS_WAVES / std::max<size_t>(1, act_min)));
+            }
         }
         win_jobs = win;
         size_t cur = 0;
@@ -665,10 +668,10 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         // whatever their number, so the more the better)
         // fill_regs.hip deals the launch's waves to the reads' contigs densely (a team's waves sit in any workgroups): the launch holds
         // what the chip's wave slots hold
-        const size_t regs_wave_slots = regs_wave_cap ? regs_wave_cap : (size_t)c.n_cus * (size_t)std::max(c.regs_wg_per_cu, 0) * REGS_WAVES;
+        const size_t regs_wave_slots = regs_G ? (regs_wave_cap ? regs_wave_cap : (size_t)c.n_cus * (size_t)std::max(c.regs_wg_per_cu, 0) * REGS_WAVES)
+                                              : (size_t)c.n_cus * (size_t)std::max(c.regs32_wg_per_cu, 0) * REGS_WAVES;
         size_t regs_waves_used = 0;
-        if (regs_G) max_jobs = 4096;
-        else if (regs32_G > 1) max_jobs = std::max<size_t>(1, (size_t)c.n_cus * (size_t)c.regs32_wg_per_cu / regs32_G);
+        if (regs_G || regs32_G) max_jobs = 4096;
         else if (fast) {
             uint32_t tiles = 0; for (uint32_t a : jobs[k0].act) tiles += (c.al[a].m + 255) / 256;
             g_min = local16_min_g(c, jobs[k0]);
@@ -685,9 +688,9 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         const size_t per_job = sizeof(JobView) + sizeof(WalkArgs) + 512 + 8ull * c.C;     // the launch's job table (and wave map), after the jobs' own buffers
         while (k1 < jobs.size() && used + lay[k1].stride + per_job + view_room <= win_bytes && (k1 - k0) < max_jobs &&
-               (k1 == k0 || (regs32_G ? regs32_plan(c, jobs[k1]) == regs32_G : regs_G ? regs_plan(c, jobs[k1]) > 0 : (regs_plan(c, jobs[k1]) == 0 || !fast))) &&
-               (!regs_G || k1 == k0 || regs_waves_used + lay[k1].nact <= regs_wave_slots)) {
-            if (regs_G) regs_waves_used += lay[k1].nact;
+               (k1 == k0 || (regs32_G ? regs32_plan(c, jobs[k1]) > 0 : regs_G ? regs_plan(c, jobs[k1]) > 0 : (regs_plan(c, jobs[k1]) == 0 || !fast))) &&
+               ((!regs_G && !regs32_G) || k1 == k0 || regs_waves_used + lay[k1].nact <= regs_wave_slots)) {
+            if (regs_G || regs32_G) regs_waves_used += lay[k1].nact;
             if (fast && !regs_G && !regs32_G && k1 > k0) {
                 // a later job may need MORE workgroups than the first (shorter read, more contigs): all workgroups of the launch
                 // must still be resident at once
@@ -760,7 +763,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         JobView* d_views = (JobView*)tail; tail += align_up(sizeof(JobView) * nj, 256);
         WalkArgs* d_wargs = (WalkArgs*)tail; tail += align_up(sizeof(WalkArgs) * nj, 256);
         std::vector<uint2> wave_map;                     // fill_regs.hip: wave of the grid -> (read of the launch, active contig)
-        if (regs_G) for (uint32_t q = 0; q < nj; ++q) for (uint32_t k = 0; k < lay[k0 + q].nact; ++k) wave_map.push_back(make_uint2(q, k));
+        if (regs_G || regs32_G) for (uint32_t q = 0; q < nj; ++q) for (uint32_t k = 0; k < lay[k0 + q].nact; ++k) wave_map.push_back(make_uint2(q, k));
         uint2* d_wave_map = (uint2*)tail; tail += align_up(sizeof(uint2) * wave_map.size(), 256);
         if ((size_t)(tail - c.arena) > win_base + win_bytes) return fail(STITCH_EINTERNAL, "arena overflow");
         Ln.d_views = d_views; Ln.d_wargs = d_wargs;
@@ -818,7 +821,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         const uint32_t kind = regs_G ? 2u : regs32_G ? 3u : fast ? 1u : 0u;
         Ln.G = G; Ln.kind = kind; Ln.waves = waves; Ln.slots_cap = slots_cap; Ln.g_min = g_min;
-        if (kind == 3u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs32(d_views, nj, G, mx, c.opts.circular != 0, sh, sA); }
+        if (kind == 3u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs32(d_views, d_wave_map, (uint32_t)wave_map.size(), mx, c.opts.circular != 0, sh, sA); }
         else if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, d_wave_map, (uint32_t)wave_map.size(), REGS_WAVES, mx, c.opts.circular != 0, sh, sA); }
         else if (kind == 1u) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, sA);
         else launch_fill(d_views, nj, waves, sh, sA);

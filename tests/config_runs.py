@@ -54,10 +54,10 @@ def main():
         batch = args.batch or 1000
     elif args.config == "cfg2":
         db = synth.make_db(50, 5000, 1001)
-        n_reads = args.reads or (320 if args.mode == "local" else 152)
+        n_reads = args.reads or (320 if args.mode == "local" else 160)
         reads = synth.make_reads(db, n_reads, 10000, 44)
         opts = dict(mode=args.mode)
-        batch = args.batch or (160 if args.mode == "local" else 76)       # four launches per call: 40 reads x 50 contigs fill fill_regs' 2048 wave slots, 19 reads fill_regs32's 256 workgroups
+        batch = args.batch or (160 if args.mode == "local" else 80)       # four launches per call: 40 reads x 50 contigs fill fill_regs' 2048 wave slots, 20 reads fill_regs32's 1024
     elif args.config == "cfg3":
         db = synth.make_db(50, 5000, 1001)
         n_reads = args.reads or 2048
