@@ -10,7 +10,7 @@
 //       so the points within w columns of cc are a range s_lo .. s_hi found by two divisions, and the rows are those of its ends.
 // Then the band goes to global memory as uint16 (the score kernels' format) and the pair's class is decided: every column fits
 // the register window and the first row never decreases -> BAND_CLASS_WINDOW; some column taller than the LDS ring -> _TALL;
-// else _RING.  tests/test_prealign.py compares the band drawn here with the oracle's, column by column.
+// else _RING; the classes are counted, so that the host launches only the score kernels that have pairs.  tests/test_prealign.py compares the band drawn here with the oracle's, column by column.
 #include <hip/hip_runtime.h>
 
 #include "prealign.h"
@@ -28,7 +28,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 constexpr uint32_t BAND_DEVICE_MAX_COLS = 8192;      // columns 0 .. n in 64 KB of LDS
 
 __global__ __launch_bounds__(64) void band_draw_kernel(const BandPair* __restrict__ pairs, const uint32_t* __restrict__ which, const BandElem* __restrict__ elems,
-                                                       uint32_t w_, uint32_t ring_rows, uint32_t window_rows, uint16_t* __restrict__ bands, uint32_t* __restrict__ cls) {
+                                                       uint32_t w_, uint32_t ring_rows, uint32_t window_rows, uint16_t* __restrict__ bands, uint32_t* __restrict__ cls,
+                                                       uint32_t* __restrict__ class_counts) {
     extern __shared__ uint32_t band_lds[];
     const uint32_t pid = which[blockIdx.x];
     const BandPair P = pairs[pid];
@@ -86,17 +87,21 @@ __global__ __launch_bounds__(64) void band_draw_kernel(const BandPair* __restric
         run_max = max(run_max, (uint32_t)__shfl((int)incl, 63, 64));
     }
     tall = wave_max_u32(tall); bad = wave_max_u32(bad);
-    if (lane == 0) cls[pid] = !bad ? BAND_CLASS_WINDOW : tall ? BAND_CLASS_TALL : BAND_CLASS_RING;
+    if (lane == 0) {
+        const uint32_t k = !bad ? BAND_CLASS_WINDOW : tall ? BAND_CLASS_TALL : BAND_CLASS_RING;
+        cls[pid] = k;
+        if (class_counts) atomicAdd(class_counts + k, 1u);          // (the host launches only the score kernels that have pairs)
+    }
 }
 
 uint32_t band_device_max_cols() { return BAND_DEVICE_MAX_COLS; }
 // `window` false: no pair is offered to the register-window kernel (its scoring range does not hold, or it is switched off)
 void launch_band_draw(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, uint32_t max_n, const BandElem* d_elems, uint32_t w, uint32_t ring_rows,
-                      bool window, uint16_t* d_bands, uint32_t* d_cls, hipStream_t stream) {
+                      bool window, uint16_t* d_bands, uint32_t* d_cls, uint32_t* d_class_counts, hipStream_t stream) {
     if (!n_pairs) return;
     const size_t lds = 8ull * (max_n + 1);
     (void)hipFuncSetAttribute((const void*)band_draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(band_draw_kernel, dim3(n_pairs), dim3(64), lds, stream, d_pairs, d_which, d_elems, w, ring_rows, window ? 256u : 0u, d_bands, d_cls);
+    hipLaunchKernelGGL(band_draw_kernel, dim3(n_pairs), dim3(64), lds, stream, d_pairs, d_which, d_elems, w, ring_rows, window ? 256u : 0u, d_bands, d_cls, d_class_counts);
 }
 
 }  // namespace stitch

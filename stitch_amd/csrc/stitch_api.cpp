@@ -40,7 +40,7 @@ bool launch_full_scores_skew16(const BandPair* d_pairs, const uint32_t* d_which,
                                const uint8_t* d_reads, const uint8_t* d_contigs, int32_t* d_scores, hipStream_t stream);
 uint32_t band_device_max_cols();
 void launch_band_draw(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, uint32_t max_n, const BandElem* d_elems, uint32_t w, uint32_t ring_rows,
-                      bool window, uint16_t* d_bands, uint32_t* d_cls, hipStream_t stream);
+                      bool window, uint16_t* d_bands, uint32_t* d_cls, uint32_t* d_class_counts, hipStream_t stream);
 bool band_fits_window(const uint16_t* lo, const uint16_t* hi, uint32_t m, uint32_t n);
 bool window_scoring_ok(const BandScoring& sc, uint32_t max_m);
 void launch_banded_scores_window(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads,
@@ -126,6 +126,7 @@ struct stitch_ctx {
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the banded kernel, concurrent with the full-matrix kernel
     hipStream_t stream3 = nullptr;                     // the fills of the second arena window (two fills in flight: run_jobs_in_order)
     hipEvent_t ev2[2] = {nullptr, nullptr};
+    uint32_t* pin_cnt = nullptr;                       // pre-alignment: the band kernel's class counts of the two chunks in flight (pinned)
     hipStream_t pstream[3] = {nullptr, nullptr, nullptr};      // the pre-alignment filter's streams
     hipEvent_t evu[2] = {nullptr, nullptr};     // pre-alignment: a chunk's uploads are done
     hipEvent_t evc[2] = {nullptr, nullptr};     // pre-alignment: end of the device work of the chunk in each of the two chunk regions
@@ -248,6 +249,7 @@ void stitch_ctx_destroy(stitch_ctx* c) {
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_h2d) (void)hipHostFree(c->pin_h2d);
     for (auto* b : c->pin_bands) if (b) (void)hipHostFree(b);
+    if (c->pin_cnt) (void)hipHostFree(c->pin_cnt);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& w : c->evp) for (auto& e : w) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev2) if (e) (void)hipEventDestroy(e);
@@ -1094,6 +1096,8 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
     uint32_t* d_fids = (uint32_t*)p0; p0 += al256(NP * 4);
     int32_t* d_fscores = (int32_t*)p0; p0 += al256(NP * 4);
     uint32_t* d_cls = (uint32_t*)p0; p0 += al256(NP * 4);
+    uint32_t* d_cnt = (uint32_t*)p0; p0 += 256;                        // class counts of the two chunks in flight (4 words each)
+    if (!c.pin_cnt) HIP_TRY(hipHostMalloc((void**)&c.pin_cnt, 64, hipHostMallocDefault));
     // the bands: drawn and classified on the device from the backbone's pieces (prealign_band.hip), or, for targets beyond that
     // kernel's LDS and on request, on the host
     const bool dev_bands = !c.knobs.prealign_v1 && !c.knobs.host_bands && !c.knobs.banded_global && max_n + 1 <= band_device_max_cols();
@@ -1257,16 +1261,26 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         if (!S.banded_ids.empty()) HIP_TRY(hipMemcpyAsync(d_banded, S.banded_ids.data(), S.banded_ids.size() * 4, hipMemcpyHostToDevice, up));
         if (!S.tall_ids.empty()) HIP_TRY(hipMemcpyAsync(d_tall, S.tall_ids.data(), S.tall_ids.size() * 4, hipMemcpyHostToDevice, up));
         if (!S.win_ids.empty()) HIP_TRY(hipMemcpyAsync(d_win, S.win_ids.data(), S.win_ids.size() * 4, hipMemcpyHostToDevice, up));
-        HIP_TRY(hipEventRecord(c.evu[i & 1], up));
-        HIP_TRY(hipStreamWaitEvent(PS1, c.evu[i & 1], 0));
-        if (dev_bands) {          // every pair with a band is in `banded_ids`; the band kernel draws the band and names the score kernel, each of which skips the others' pairs
+        if (dev_bands) {
+            // every pair with a band is in `banded_ids`; the band kernel (on the upload stream: beside the score kernels of the chunk
+            // before) draws the bands, names each pair's score kernel and counts the classes; the host waits for the counts and launches
+            // only the score kernels that have pairs (an empty one still costs its launch and 5000 workgroups that come and go: 3 ms
+            // of the 13 a chunk took), each of which skips the others' pairs
             const uint32_t nb = (uint32_t)S.banded_ids.size();
-            launch_band_draw(d_pairs, d_banded, nb, max_n, d_elems, (uint32_t)c.opts.band_width, banded_ring_rows(), win_scoring, d_bands, d_cls, PS1);
-            if (win_scoring) launch_banded_scores_window(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_scores, d_cls, PS1);
-            if (!launch_banded_scores_lds(d_pairs, d_banded, nb, S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, d_cls, PS1))
+            uint32_t* const cnt_d = d_cnt + 4 * (i & 1); uint32_t* const cnt_h = c.pin_cnt + 4 * (i & 1);
+            HIP_TRY(hipMemsetAsync(cnt_d, 0, 16, up));
+            launch_band_draw(d_pairs, d_banded, nb, max_n, d_elems, (uint32_t)c.opts.band_width, banded_ring_rows(), win_scoring, d_bands, d_cls, cnt_d, up);
+            HIP_TRY(hipMemcpyAsync(cnt_h, cnt_d, 16, hipMemcpyDeviceToHost, up));
+            HIP_TRY(hipEventRecord(c.evu[i & 1], up));
+            HIP_TRY(hipEventSynchronize(c.evu[i & 1]));
+            HIP_TRY(hipStreamWaitEvent(PS1, c.evu[i & 1], 0));
+            if (cnt_h[BAND_CLASS_WINDOW]) launch_banded_scores_window(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_scores, d_cls, PS1);
+            if (cnt_h[BAND_CLASS_RING] && !launch_banded_scores_lds(d_pairs, d_banded, nb, S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, d_cls, PS1))
                 launch_banded_scores(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, d_cls, BAND_CLASS_RING, PS1);
-            launch_banded_scores(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, d_cls, BAND_CLASS_TALL, PS1);
+            if (cnt_h[BAND_CLASS_TALL]) launch_banded_scores(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, d_cls, BAND_CLASS_TALL, PS1);
         } else {
+            HIP_TRY(hipEventRecord(c.evu[i & 1], up));
+            HIP_TRY(hipStreamWaitEvent(PS1, c.evu[i & 1], 0));
             if (!S.win_ids.empty()) launch_banded_scores_window(d_pairs, d_win, (uint32_t)S.win_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_scores, nullptr, PS1);
             if (c.knobs.banded_global || !launch_banded_scores_lds(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, nullptr, PS1))
                 launch_banded_scores(d_pairs, d_banded, (uint32_t)S.banded_ids.size(), sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, nullptr, 0, PS1);
@@ -1609,7 +1623,7 @@ int stitch_prealign_band_device(int device, const uint8_t* read, uint32_t read_l
     HIP_TRY(hipMalloc((void**)&B.b, 4ull * (target_len + 1))); HIP_TRY(hipMalloc((void**)&B.c, 4));
     HIP_TRY(hipMemcpy(B.p, &P, sizeof(P), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(B.w, &zero, 4, hipMemcpyHostToDevice));
     if (!el.empty()) HIP_TRY(hipMemcpy(B.e, el.data(), el.size() * sizeof(BandElem), hipMemcpyHostToDevice));
-    launch_band_draw(B.p, B.w, 1, target_len, B.e, w, banded_ring_rows(), true, B.b, B.c, nullptr);
+    launch_band_draw(B.p, B.w, 1, target_len, B.e, w, banded_ring_rows(), true, B.b, B.c, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(lo, B.b, 2ull * (target_len + 1), hipMemcpyDeviceToHost));
