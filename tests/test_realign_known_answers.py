@@ -30,7 +30,14 @@ One circular plasmid P of 40 bases (no 5-mer twice), CLI scoring (match 1, misma
    22 > 20, what traceback_from(n, A) returns (:419) — but the rule also wants the OLD chain to end on that contig
    (`best_alignment.end_contig_idx == contig_idx`, :423), and it ends on B: rejected.  The second rotation (at y = 15, the first base not
    on A: B[10:25] + A[33:40] + A[0:15]) ends best on A with 15 - 10 + 7 + 15 = 27 but starts on B: rejected too.  The chain stays
-   15=1C5j15= with score 20."""
+   15=1C5j15= with score 20.
+6. traceback_all (traceback/mod.rs:152-217) and the suboptimal filter (aligners/mod.rs:318-329), linear contigs A, B and C = forty N
+   (equal to no base of the read), read = A[5:25] + B[5:35], --suboptimal.  Best chain: 20 matches, jump, 30 matches = 40, ends on B; it
+   marks A (start) and B (end, jumped to) as seen.  C is left: the best cell of C is in the LAST column — a cell of column j takes the
+   jump from the best cell of column j - 1 (a B cell with 10 + (j - 21) for j > 20) and mismatches: cmax(j-1) - 10 - 4, largest at j = 50:
+   39 - 14 = 25 (a diagonal step inside C would cost another -4, clipping the read earlier loses a base of B) — in every row alike, equal
+   lengths, so the x-suffix rule (:406-429, a later row only on a longer length) keeps row 1: 20 matches, Xjump(B, 5), 29 matches,
+   Xjump(C, 0), one substitution = 25 >= 20 % of 40: the second chain.  With A and B alone both are seen after the first chain: one chain."""
 import json
 import os
 
@@ -48,6 +55,8 @@ def expand(ops):
     for o in ops:
         if o[0] == "M":
             out += [(0, 0, 0)] * o[1]
+        elif o[0] == "X":
+            out += [(1, 0, 0)] * o[1]
         else:
             out.append((6, o[1], o[2]))
     return out
@@ -98,6 +107,29 @@ def test_product_keeps_the_accept_rules_asymmetry(case):
     chains, _ = al.align([case["read"]])[0]
     assert len(chains) == 1
     check(chains[0], case["want"], lambda c: c.operations)
+
+
+ALL = VEC["traceback_all_cases"]
+
+
+@pytest.mark.parametrize("case", ALL, ids=[c["name"] for c in ALL])
+def test_oracle_reproduces_the_hand_traced_suboptimal_chains(case):
+    o = orc.Aligners([tuple(t) for t in case["targets"]], suboptimal=True)
+    chains = o.align(case["read"])
+    assert len(chains) == len(case["want"])
+    for c, w in zip(chains, case["want"]):
+        check(c, w, lambda c: c.ops)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ALL, ids=[c["name"] for c in ALL])
+def test_product_reproduces_the_hand_traced_suboptimal_chains(case):
+    import stitch_amd
+    al = stitch_amd.Builder(suboptimal=True).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in case["targets"]], device=0)
+    chains, _ = al.align([case["read"]])[0]
+    assert len(chains) == len(case["want"])
+    for c, w in zip(chains, case["want"]):
+        check(c, w, lambda c: c.operations)
 
 
 def test_the_plasmid_has_no_repeats():
