@@ -27,10 +27,15 @@ constexpr int32_t NONE_V = -(1 << 29), NONE_KEY = -(1 << 30);
 constexpr uint32_t WIN_ROWS = 256;
 
 __device__ __forceinline__ int32_t prefix_max_incl(int32_t v) {            // inclusive prefix maximum over the 64 lanes
-#define STITCH_DPP_STEP(CTRL, ROWMASK) { const int32_t o = __builtin_amdgcn_update_dpp(NONE_KEY, v, CTRL, ROWMASK, 0xF, false); v = o > v ? o : v; }
-    STITCH_DPP_STEP(0x111, 0xF) STITCH_DPP_STEP(0x112, 0xF) STITCH_DPP_STEP(0x114, 0xF) STITCH_DPP_STEP(0x118, 0xF)      // row_shr 1, 2, 4, 8
-    STITCH_DPP_STEP(0x142, 0xA) STITCH_DPP_STEP(0x143, 0xC)                                                          // row_bcast 15, 31
-#undef STITCH_DPP_STEP
+    // v_max_i32 with a DPP source and bound_ctrl off: a lane whose source does not exist keeps its value, which is what a maximum with
+    // "nothing" is - one instruction per step where `old value + v_mov_dpp + v_max` are three.  (The s_nop 1 are the two wait states
+    // between a vector write and a DPP read of the same register: the compiler does not look into inline assembly.)
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(v));
     return v;
 }
 __device__ __forceinline__ int32_t from_lane_above(int32_t v, int32_t first) {      // lane l takes lane l - 1's value, lane 0 `first`
