@@ -107,7 +107,9 @@ typedef struct stitch_timing { double fill_ms, walk_ms, h2d_ms, d2h_ms, host_ms;
                                double fill_kernel_ms /* sum of the fill kernels' own durations (what a profiler lists per dispatch).  fill_ms is the time during
                                   which a fill kernel was RUNNING: with two launches in flight (the next one takes the slots finished reads free) the
                                   two differ */; } stitch_timing;
-int stitch_last_timing(const stitch_ctx*, stitch_timing* out);
+/* `out_size` = sizeof(stitch_timing) as the CALLER was compiled: the library copies min(out_size, its own size) bytes, so the struct can
+ * grow at its end without overrunning a binding built against an older header (fields are only ever appended). */
+int stitch_last_timing(const stitch_ctx*, stitch_timing* out, size_t out_size);
 
 /* Test hook (host only, no device needed): the band of the pre-alignment filter for one (read, target strand) pair as the
  * library computes it — rows [lo[c], hi[c]) for the columns c = 0..target_len.  Returns 1 when the band is the full matrix

@@ -387,5 +387,5 @@ class Aligners:
 
     def timing(self):
         t = _Timing()
-        _check(lib().stitch_last_timing(self.h, C.byref(t)))
+        _check(lib().stitch_last_timing(self.h, C.byref(t), C.c_size_t(C.sizeof(t))))
         return {f: getattr(t, f) for f, _ in _Timing._fields_}

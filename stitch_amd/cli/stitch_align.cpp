@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -464,10 +465,17 @@ int main(int argc, char** argv) {
             if (pid == 0) { std::vector<char*> cv; for (auto& x : av) cv.push_back(&x[0]); cv.push_back(nullptr); execv("/proc/self/exe", cv.data()); _exit(127); }
             run.pids.push_back(pid);
         }
-        for (pid_t& p : run.pids) {                     // (after a failure the guard above ends the workers that are still running)
-            if (failed) break;
-            int st = 0; if (waitpid(p, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { failed = true; why = "a worker process failed"; }
-            p = -1;
+        // Reap the workers in whatever order they end: with --index-via rccl a worker that dies early (bad ordinal, hipMalloc) leaves the
+        // others inside ncclCommInitRank / ncclBroadcast, whose bootstrap has no timeout — waiting for rank 0 first would hang for good.
+        // The first failure ends the rest (cleanup() below: SIGTERM, then reaped).
+        for (size_t left = run.pids.size(); left > 0 && !failed;) {
+            int st = 0; const pid_t p = waitpid(-1, &st, 0);
+            if (p < 0) { if (errno == EINTR) continue; failed = true; why = "waitpid failed"; break; }
+            const auto it = std::find(run.pids.begin(), run.pids.end(), p);
+            if (it == run.pids.end()) continue;          // (not one of the workers)
+            const size_t rank = (size_t)(it - run.pids.begin());
+            *it = -1; --left;
+            if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { failed = true; why = "worker " + std::to_string(rank) + " failed (" + (WIFEXITED(st) ? "exit status " + std::to_string(WEXITSTATUS(st)) : "signal " + std::to_string(WTERMSIG(st))) + ")"; }
         }
         if (failed) { run.cleanup(); die(why); }         // (exit() does not unwind: clean up first)
         for (uint32_t r = 0; r < W; ++r) {                 // records in rank order = input order
@@ -480,6 +488,9 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (worker) { if (!freopen(a.shard_out.c_str(), "w", stdout)) die("cannot write " + a.shard_out); out.bam = false; }
+    // test hook: the worker of this device ordinal stalls before it touches a device, like a rank held inside an RCCL bootstrap whose
+    // partner has died (tests/test_cli.py: the parent must end it and return promptly)
+    if (worker) { const char* st = getenv("STITCH_ALIGN_TEST_STALL_DEVICE"); if (st && atoi(st) == a.device) for (;;) pause(); }
     stitch_ctx* ctx = nullptr;
     if (stitch_ctx_create(a.device, index, &a.o, &ctx) != STITCH_OK) die(stitch_last_error());
 

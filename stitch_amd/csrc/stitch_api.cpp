@@ -1664,9 +1664,10 @@ long stitch_split_at_y(const stitch_chain* in, const stitch_op* in_ops, int32_t 
     return (long)r.ops.size();
 }
 
-int stitch_last_timing(const stitch_ctx* c, stitch_timing* out) {
+int stitch_last_timing(const stitch_ctx* c, stitch_timing* out, size_t out_size) {
     if (!c || !out) return fail(STITCH_EINVAL, "null argument");
-    *out = c->tm;
+    // the struct only ever grows at its end: a caller built against an older header gets the fields it knows, never more bytes than it has
+    std::memcpy(out, &c->tm, out_size < sizeof(stitch_timing) ? out_size : sizeof(stitch_timing));
     return STITCH_OK;
 }
 

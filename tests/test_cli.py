@@ -232,6 +232,24 @@ def test_a_failing_worker_leaves_nothing_behind(cli, tmp_path):
     assert not [p for p in os.listdir("/tmp") if p.startswith("stitch-align-")]
 
 
+def test_a_worker_that_dies_ends_a_stalled_one_promptly(cli, tmp_path):
+    """the parent reaped its workers in rank order, so a rank stuck for good (inside an RCCL bootstrap whose partner
+    died) held it forever.  Here the worker of device 5 stalls (test hook) and the other cannot start (no such device / no GPU): the
+    parent must report the failure, end the stalled worker and remove its files within seconds.  Runs without a GPU."""
+    import time
+    from stitch_amd import synth
+    db = synth.make_db(2, 300, 5)
+    ref = tmp_path / "ref.fa"; ref.write_text("".join(f">{n}\n{s.decode()}\n" for n, s in db))
+    fq = tmp_path / "r.fq"; fq.write_text("".join(f"@r{k}\n{r.decode()}\n+\n{'I' * len(r)}\n" for k, r in enumerate(synth.make_reads(db, 6, 120, 3))))
+    before = set(p for p in os.listdir("/tmp") if p.startswith("stitch-align-"))
+    t0 = time.time()
+    r = subprocess.run([cli, "-f", str(fq), "-r", str(ref), "--devices", "5,97"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, STITCH_ALIGN_TEST_STALL_DEVICE="5"), timeout=120)
+    assert r.returncode != 0 and b"worker 1 failed" in r.stderr, r.stderr.decode()[-800:]
+    assert time.time() - t0 < 60
+    assert set(p for p in os.listdir("/tmp") if p.startswith("stitch-align-")) <= before
+
+
 @pytest.mark.gpu
 def test_index_broadcast_over_rccl(cli, tmp_path):
     """`--index-via rccl`: the workers get the reference index through a native ncclBroadcast from rank 0 instead of reading the blob
