@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--contig-len", type=int, default=5000)
     ap.add_argument("--cpu-reads", type=int, default=-1, help="0 = skip the cpu_baseline leg")
     ap.add_argument("--cpu-reads-per-worker", type=int, default=2, help="timed reads per worker thread of the CPU leg (>= 2; one more is aligned as warm-up)")
-    ap.add_argument("--cpu-prefix", type=int, default=400, help="bases of each sample read the CPU aligns (0 = whole read: 40 GB and minutes per read)")
+    ap.add_argument("--cpu-prefix", type=int, default=1000, help="bases of each sample read the CPU aligns (0 = WHOLE reads: 40 GB of 16-byte cells per worker and ~100 s per read and thread; the default keeps the CPU leg at about a minute; profiles/r04_cpu_whole_reads.json holds a whole-read run)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="worker threads of the CPU leg (0 = min(cores, free RAM / RAM per worker, CPU share of the box))")
     args = ap.parse_args()
 
@@ -136,6 +136,7 @@ def main():
     clk_cycles = clk_ticks = 0
     cells = 0
     launches = 0
+    fallbacks = 0
     mapped = 0
     n_mine = 0
     kernel_name = None
@@ -143,7 +144,7 @@ def main():
         rr, ch, _ops = aligners.align_packed_raw(*batches[s])       # result arena views: what a compiled front end would read
         tm = aligners.timing()
         fill_ms += tm["fill_ms"]; walk_ms += tm["walk_ms"]; cells += tm["cells"]; launches += tm["launches"]; fill_kernel_ms += tm.get("fill_kernel_ms", tm["fill_ms"])
-        clk_cycles += tm.get("clk_shader_cycles", 0); clk_ticks += tm.get("clk_ref_ticks", 0)
+        clk_cycles += tm.get("clk_shader_cycles", 0); clk_ticks += tm.get("clk_ref_ticks", 0); fallbacks += tm.get("fallbacks", 0)
         kernel_name = FILL_KERNELS.get(tm.get("fill_kind", 1), kernel_name)
         n_mine += my_reads[s]
         if len(ch):
@@ -166,7 +167,14 @@ def main():
         prop = torch.cuda.get_device_properties(local_rank)
         # roofline of the dominant kernel (this rank's launches; every rank runs the same kernel on the same shape)
         fill_s = fill_ms / 1e3
-        achieved = (cells * 1.0 / fill_s) / 1e9 if fill_s > 0 else 0.0           # GB/s at 1 algorithmic byte per cell
+        # `achieved` is anchored on the WALL time of the timed steps: this rank's algorithmic bytes (1 per cell) / dt.
+        # It needs no builder-side timer, includes walks, copies and host work between launches, and is what the driver's clock
+        # around the run can check.  The busy-union figure (bytes / time during which a fill kernel was running) is kept as
+        # `achieved_fill_busy`, the per-dispatch one as `achieved_per_dispatch` (x launches_in_flight = the busy figure).
+        achieved = (cells * 1.0 / dt) / 1e9 if dt > 0 else 0.0                     # GB/s at 1 algorithmic byte per cell
+        achieved_busy = (cells * 1.0 / fill_s) / 1e9 if fill_s > 0 else 0.0
+        achieved_disp = (cells * 1.0 / (fill_kernel_ms / 1e3)) / 1e9 if fill_kernel_ms > 0 else 0.0
+        cells_per_read = args.read_len * args.contigs * args.contig_len
         out = {
             "metric": "reads_per_sec", "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -176,17 +184,25 @@ def main():
                        "reads_per_step_per_gpu": R, "cells_per_read": args.read_len * args.contigs * args.contig_len,
                        "scoring": "A=1 B=-4 O=-6 E=-2 J=-10", "sharding": "one read stream cut by rank at read-group boundaries, index broadcast once"},
             "gcells_per_sec": cells_all / dt / 1e9,
+            # `value` counts every input read, also the consecutive duplicates the reference aligns once (FastxGroupingIterator: every 50th
+            # read of the synthetic set costs nothing); the rate by DP cells actually filled, in reads of the named shape:
+            "reads_per_sec_by_cells": cells_all / dt / cells_per_read,
             "device": {"name": prop.name, "cus": prop.multi_processor_count, "hbm_gib": round(prop.total_memory / 2**30)},
             "mapped_fraction": mapped / float(max(1, n_mine)),
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "achieved_is": "this rank's algorithmic bytes / wall time of the timed steps",
+                         "achieved_fill_busy": achieved_busy, "frac_fill_busy": achieved_busy / HBM_PEAK_GBS,
+                         "achieved_per_dispatch": achieved_disp, "frac_per_dispatch": achieved_disp / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_cell": 1.0, "cells_per_launch": cells / max(1, launches),
                          # two launches are in flight (the next one takes the workgroup slots that finished reads of the current one free): a
                          # kernel's own duration (what rocprofv3 lists per dispatch) is longer than the time the launch adds to the job.
                          # `achieved` = algorithmic bytes / time during which the fill kernel was running (no double counting).
                          "avg_launch_ms": fill_kernel_ms / max(1, launches), "fill_busy_ms_per_launch": fill_ms / max(1, launches),
                          "launches_in_flight": fill_kernel_ms / fill_ms if fill_ms > 0 else 1.0, "walk_kernel_ms_per_step": walk_ms / args.steps,
-                         "fill_gcells_per_sec": cells / fill_s / 1e9 if fill_s > 0 else 0.0},
+                         "fill_gcells_per_sec": cells / fill_s / 1e9 if fill_s > 0 else 0.0,
+                         # launches repeated on a slower kernel after a partner timeout (co-residency lost): must be 0 in a healthy run
+                         "fill_fallbacks": fallbacks},
         }
         # the shader clock the fill ran at, measured inside the kernel over the timed launches (s_memtime against the 100 MHz
         # s_memrealtime; fill_regs.hip).  The issue roofline below is priced at the nominal 2.4 GHz AND at this clock.
@@ -260,6 +276,7 @@ def cpu_leg(args, db, stream, aligners):
     freed, and each worker aligns >= 2 timed reads.  T = min(cores, free RAM / RAM per worker, the box's CPU share); the scaling
     from one thread up to T is measured and printed.  SAM text from both sides is diffed on the sample."""
     from oracle import oracle as orc
+    native = orc.native_lib() is not None          # g++ -O3 -march=native on THIS host (BASELINE.md 3); the portable build otherwise
     pre = args.cpu_prefix if 0 < args.cpu_prefix < args.read_len else args.read_len
     rows = args.contigs * (args.contig_len + 1)
     ram_per_worker = rows * (pre + 1) * 16                      # traceback/mod.rs:122-126
@@ -279,13 +296,13 @@ def cpu_leg(args, db, stream, aligners):
     targets = [(n, s) for n, s in db]
     cells_per_read = args.read_len * args.contigs * args.contig_len
     # scaling: one thread, a few, all — each level times `per_worker` reads per worker after one warm-up read per worker
-    levels = sorted({1, min(4, T), T})
+    levels = sorted({1, T})
     scaling = []
     secs = ccells = 0
     csam = busy = None
     for t in levels:
         sample = cut[:per_worker * t]
-        secs, ccells, _scores, csam, busy = orc.cpu_bench_sam(targets, sample, threads=t, name_base=0, chunk=1, warm=1)
+        secs, ccells, _scores, csam, busy = orc.cpu_bench_sam(targets, sample, threads=t, name_base=0, chunk=1, warm=1, native=True)
         scaling.append({"threads": t, "reads": len(sample), "seconds": round(secs, 2), "mcells_per_sec": round(ccells / secs / 1e6, 1),
                         "mcells_per_sec_per_thread": round(ccells / secs / 1e6 / t, 1)})
     sample = cut[:per_worker * T]
@@ -300,13 +317,14 @@ def cpu_leg(args, db, stream, aligners):
     return {"value": ccells / secs / cells_per_read, "unit": "reads/s", "cores": T, "kind": "port", "warm": True,
             "gcells_per_sec": ccells / secs / 1e9, "mcells_per_sec_per_thread": per_thread, "scaling": scaling,
             "sam_identical_on_sample": bool(all(same)), "sam_reads_compared": len(same),
-            "sample": f"first {pre} bp of the first {len(sample)} distinct reads vs the full DB, {per_worker} timed reads per worker after one warm-up read per "
+            "sample": f"{'WHOLE reads: the' if pre == args.read_len else 'first ' + str(pre) + ' bp of the'} first {len(sample)} distinct reads vs the full DB, {per_worker} timed reads per worker after one warm-up read per "
                       f"worker (matrices allocated and touched before the clock; the clock stops before they are freed): {ccells} cells in {secs:.1f} s on {T} "
                       f"worker threads = {per_thread:.1f} Mcells/s per thread (one aligner set per thread, one record per pull; {cores} cores visible, CPU share "
                       f"of the box {share}, {free / 2**30:.0f} GiB host RAM available, {ram_per_worker / 2**30:.1f} GiB of 16-byte traceback cells per worker; "
                       f"T = min(cores, RAM / per-worker RAM, share)); scaling {', '.join(str(x['threads']) + ' thr: ' + str(x['mcells_per_sec']) + ' Mcells/s' for x in scaling)}"
                       f"{why}; reads/s = cells/s / {cells_per_read} cells per {args.read_len} bp read; C++ restatement of fulcrumgenomics/stitch "
-                      f"(g++ -O3, portable flags), not the Rust binary"}
+                      f"({'g++ -O3 -march=native, built on this host' if native else 'g++ -O3, portable flags'}), not the Rust binary",
+            "build": "g++ -O3 -march=native (this host)" if native else "g++ -O3 (portable)", "whole_reads": pre == args.read_len}
 
 
 if __name__ == "__main__":

@@ -28,6 +28,42 @@ def build(force=False):
 _lib = None
 
 
+def _declare(L):
+    L.orc_last_error.restype = C.c_char_p
+    for name in ("orc_single", "orc_mc_custom", "orc_mc_traceback_all", "orc_mc_traceback_from", "orc_chain",
+                 "orc_aln_cigar", "orc_aln_split_at_y", "orc_aln_earliest_x", "orc_aln_latest_x", "orc_al_align",
+                 "orc_al_chain", "orc_al_format_sam"):
+        getattr(L, name).restype = C.c_long
+    L.orc_mc_new.restype = C.c_void_p
+    L.orc_al_new.restype = C.c_void_p
+    L.orc_al_cells.restype = C.c_uint64
+    L.orc_bench.restype = C.c_double
+    L.orc_bench_warm.restype = C.c_double
+    return L
+
+
+_native = None
+NATIVE_FLAGS = ["-O3", "-march=native", "-std=c++17", "-fPIC", "-fwrapv", "-shared", "-pthread"]
+
+
+def native_lib():
+    """The same sources built `-O3 -march=native` ON THE MACHINE THAT RUNS THE BENCH, into a temporary directory:
+    the portable liboracle.so travels with the repo to a host whose CPU this container does not know, a native build must not.
+    bench.py's cpu_baseline leg times this one; returns None when the host has no g++ (the portable build is timed then)."""
+    global _native
+    if _native is None:
+        import tempfile
+        d = tempfile.mkdtemp(prefix="stitch_oracle_native_")
+        out = os.path.join(d, "liboracle_native.so")
+        srcs = [os.path.join(HERE, f) for f in ("stitch_oracle.cpp", "oracle_capi.cpp", "prealign_oracle.cpp")]
+        try:
+            subprocess.check_call([os.environ.get("CXX", "g++")] + NATIVE_FLAGS + ["-o", out] + srcs, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            _native = _declare(C.CDLL(out))
+        except (OSError, subprocess.CalledProcessError):
+            _native = False
+    return _native or None
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -282,7 +318,7 @@ def cpu_bench(targets, reads, threads=1, **opts):
     return secs, int(cells.value), scores
 
 
-def cpu_bench_sam(targets, reads, threads=1, name_base=0, chunk=1, warm=1, **opts):
+def cpu_bench_sam(targets, reads, threads=1, name_base=0, chunk=1, warm=1, native=False, **opts):
     """bench.py cpu_baseline leg with the reference's worker model (`threads` workers, one aligner set each, `chunk` records
     per pull), WARM: every worker builds its aligner set and aligns `warm` read(s) before the clock starts, and the clock
     stops before anything is freed.  Returns (seconds, cells, scores, [SAM text per read], [busy seconds per worker]) — records
@@ -299,7 +335,7 @@ def cpu_bench_sam(targets, reads, threads=1, name_base=0, chunk=1, warm=1, **opt
     cap = (4 << 20) * max(1, len(reads)) + 64 * len(cat)          # (a chimeric read yields a record per segment, each with SEQ, QUAL and SA)
     buf = C.create_string_buffer(cap)
     soffs = np.zeros(len(reads) + 1, dtype=np.uint64)
-    fn = lib().orc_bench_warm
+    fn = ((native and native_lib()) or lib()).orc_bench_warm      # (native: the -march=native build of the same sources)
     fn.restype = C.c_double
     secs = fn(o, f, C.c_size_t(len(targets)), names, seqs, lens, rb,
               offs.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(len(reads)), int(threads), int(chunk), int(warm),

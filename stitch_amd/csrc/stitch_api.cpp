@@ -93,6 +93,7 @@ struct Knobs {
     size_t array_align = 0, job_align = 0;
     std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
+    int regs_waves = 0, regs_map = 0; bool trace = false;      // (experiments) waves per workgroup of fill_regs.hip, order of its wave map; launch timeline on stderr
     static Knobs from_env() {
         Knobs k;
         auto num = [](const char* name) -> unsigned long long { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : 0ull; };
@@ -110,11 +111,13 @@ struct Knobs {
         if (const char* e = getenv("STITCH_DUMP_DIR")) k.dump_dir = e;
         k.array_align = (size_t)num("STITCH_ARRAY_ALIGN"); k.job_align = (size_t)num("STITCH_JOB_ALIGN");
         k.max_waves = (int)num("STITCH_MAX_WAVES"); k.wg_per_read = (int)num("STITCH_WG_PER_READ"); k.tiles_per_wave = (int)num("STITCH_TILES_PER_WAVE");
+        k.regs_waves = (int)num("STITCH_REGS_WAVES"); k.regs_map = (int)num("STITCH_REGS_MAP"); k.trace = getenv("STITCH_TRACE") != nullptr;
         if (const char* e = getenv("STITCH_REGS_MIN_ROWS")) k.regs_min_rows = atol(e);     // (tests: 0 sends every eligible read to fill_regs.hip)
         return k;
     }
 };
 
+constexpr uint32_t REGS_WAVES_DEFAULT = 4;
 struct stitch_ctx {
     int device = 0;
     Knobs knobs;
@@ -148,6 +151,7 @@ struct stitch_ctx {
     std::vector<long> per_read;                  // read -> index into job_chains, -1 = none; for stitch_format_sam
     stitch_timing tm{};
     int n_cus = 256; uint32_t tm_wg_per_read = 1;
+    uint32_t regs_waves = 4;                     // waves per workgroup of fill_regs.hip (REGS_WAVES_DEFAULT; STITCH_REGS_WAVES for experiments)
     int regs_wg_per_cu = 0;                      // workgroups of fill_regs.hip one CU holds at once (occupancy query; 0: kernel unusable)
     int regs32_wg_per_cu = 0;                    // ... of fill_regs32.hip (one: a wave takes a SIMD's whole register file)
     bool tm_fast = false;                        // last run_jobs used the Local-mode 16-bit kernel
@@ -355,7 +359,8 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     }
     if (const char* lim = getenv("STITCH_ARENA_BYTES")) c->mem_limit = (size_t)strtoull(lim, nullptr, 10);
     c->knobs = Knobs::from_env();
-    c->regs_wg_per_cu = fill_regs_workgroups_per_cu(4);
+    c->regs_waves = (c->knobs.regs_waves == 4 || c->knobs.regs_waves == 8) ? (uint32_t)c->knobs.regs_waves : REGS_WAVES_DEFAULT;
+    c->regs_wg_per_cu = fill_regs_workgroups_per_cu(c->regs_waves);
     c->regs32_wg_per_cu = fill_regs32_workgroups_per_cu();
     *out = c.release();
     return STITCH_OK;
@@ -437,7 +442,7 @@ bool local16_ok(const stitch_ctx& c, const Job& jb) {
 // The register-resident Local-mode kernel (fill_regs.hip): one wave per active contig, REGS_WAVES waves per workgroup.  Returns the
 // workgroups a read needs (0: not applicable — a contig longer than a wave holds, a gap-extension penalty
 // too large for lane-tagged scan keys, more workgroups than the device holds at once, or a read too small to be worth a team).
-constexpr uint32_t REGS_WAVES = 4;
+constexpr uint32_t REGS_WAVES = 4;      // fill_regs32.hip: four waves per workgroup, one workgroup per CU
 uint32_t regs_plan(const stitch_ctx& c, const Job& jb) {
     if (c.knobs.no_regs || c.regs_wg_per_cu <= 0 || !local16_ok(c, jb)) return 0;
     if (c.opts.gap_extend < -1024 || c.opts.gap_open + c.opts.gap_extend < -8000) return 0;      // (16-bit insertion-chain words, fill_regs.hip)
@@ -446,7 +451,7 @@ uint32_t regs_plan(const stitch_ctx& c, const Job& jb) {
     for (uint32_t a : jb.act) { if (c.al[a].m > fill_regs_rows_per_wave()) return 0; rows += c.al[a].m; }
     const uint64_t min_rows = c.knobs.regs_min_rows >= 0 ? (uint64_t)c.knobs.regs_min_rows : 2048u;
     if (rows < min_rows) return 0;
-    const uint32_t G = ((uint32_t)jb.act.size() + REGS_WAVES - 1) / REGS_WAVES;
+    const uint32_t G = ((uint32_t)jb.act.size() + c.regs_waves - 1) / c.regs_waves;
     if (G > (uint32_t)c.n_cus * (uint32_t)c.regs_wg_per_cu) return 0;
     return G;
 }
@@ -554,7 +559,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             // the register kernel: a launch holds the reads whose contigs fill the chip's wave slots - or an equal share of the batch
             // where that leaves a remainder: a launch lasts its reads' columns however few they are, and two launches of half the
             // chip each run side by side (two windows, two streams) in the time one of them takes alone
-            const size_t slots = (size_t)c.n_cus * (size_t)c.regs_wg_per_cu * REGS_WAVES;
+            const size_t slots = (size_t)c.n_cus * (size_t)c.regs_wg_per_cu * c.regs_waves;
             size_t W = 0, act_max = 1; for (const Job& jb : jobs) { W += jb.act.size(); act_max = std::max(act_max, jb.act.size()); }
             regs_wave_cap = slots;
             if (W > slots) { const size_t nl = (W + slots - 1) / slots; regs_wave_cap = std::min(slots, (W + nl - 1) / nl + act_max); }
@@ -638,7 +643,10 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     struct Launch {
         size_t k0 = 0, k1 = 0, win_base = 0; uint32_t nj = 0, regs_G = 0, regs32_G = 0, g_min = 1, G = 1, kind = 0, slots_cap = 0; int waves = 1, slot = 0;
         std::vector<JobView> views; std::vector<WalkArgs> wargs; std::vector<size_t> base; JobView* d_views = nullptr; WalkArgs* d_wargs = nullptr;
+        double h_start = 0, h_submit = 0;                // (STITCH_TRACE) host clock at start() and at the fill's submission, ms since the call's base
     };
+    const auto t_trace0 = std::chrono::steady_clock::now();
+    auto host_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_trace0).count(); };
     // Streams.  sB: uploads, fix-up + walk, downloads.  The fills of window 0 run on c.stream, those of window 1 on c.stream3: the fill of
     // launch k + 1 is NOT ordered behind the fill of launch k.  The reads of a launch end at different times (an unalignable read keeps
     // every insertion chain alive, a clean one skips most of that work: 20-30 % apart), and a launch sized to fill the chip holds it
@@ -654,6 +662,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     auto start = [&](const size_t k0, const int slot, Launch& Ln) -> int {
         // greedy pack of consecutive jobs into the window
         size_t k1 = k0, used = 0;
+        Ln.h_start = host_ms();
         const size_t win_base = (size_t)slot * win_bytes;
         hipEvent_t* const ev = c.evp[slot];
         hipStream_t const sA = (overlap_fills && slot == 1) ? c.stream3 : c.stream;
@@ -670,7 +679,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         // whatever their number, so the more the better)
         // fill_regs.hip deals the launch's waves to the reads' contigs densely (a team's waves sit in any workgroups): the launch holds
         // what the chip's wave slots hold
-        const size_t regs_wave_slots = regs_G ? (regs_wave_cap ? regs_wave_cap : (size_t)c.n_cus * (size_t)std::max(c.regs_wg_per_cu, 0) * REGS_WAVES)
+        const size_t regs_wave_slots = regs_G ? (regs_wave_cap ? regs_wave_cap : (size_t)c.n_cus * (size_t)std::max(c.regs_wg_per_cu, 0) * c.regs_waves)
                                               : (size_t)c.n_cus * (size_t)std::max(c.regs32_wg_per_cu, 0) * REGS_WAVES;
         size_t regs_waves_used = 0;
         if (regs_G || regs32_G) max_jobs = 4096;
@@ -766,6 +775,17 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         WalkArgs* d_wargs = (WalkArgs*)tail; tail += align_up(sizeof(WalkArgs) * nj, 256);
         std::vector<uint2> wave_map;                     // fill_regs.hip: wave of the grid -> (read of the launch, active contig)
         if (regs_G || regs32_G) for (uint32_t q = 0; q < nj; ++q) for (uint32_t k = 0; k < lay[k0 + q].nact; ++k) wave_map.push_back(make_uint2(q, k));
+        if (regs_G && c.knobs.regs_map == 1 && c.regs_waves == 8 && wave_map.size() >= 16) {
+            // (experiment) eight-wave workgroups whose two waves per SIMD (waves t and t + 4) come from reads half a launch apart, as
+            // two four-wave workgroups of one CU do; entries without a wave carry a contig number no read has
+            const size_t W = wave_map.size(), half = (W / 2 + 3) / 4 * 4;
+            std::vector<uint2> m2;
+            for (size_t i = 0; 4 * i < half; ++i) for (uint32_t t = 0; t < 8; ++t) {
+                const size_t src = t < 4 ? 4 * i + t : half + 4 * i + (t - 4);
+                m2.push_back((t < 4 ? src < half : src < W) && src < W ? wave_map[src] : make_uint2(0u, 0xFFFFFFFFu));
+            }
+            wave_map.swap(m2);
+        }
         uint2* d_wave_map = (uint2*)tail; tail += align_up(sizeof(uint2) * wave_map.size(), 256);
         if ((size_t)(tail - c.arena) > win_base + win_bytes) return fail(STITCH_EINTERNAL, "arena overflow");
         Ln.d_views = d_views; Ln.d_wargs = d_wargs;
@@ -824,15 +844,17 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         const uint32_t kind = regs_G ? 2u : regs32_G ? 3u : fast ? 1u : 0u;
         Ln.G = G; Ln.kind = kind; Ln.waves = waves; Ln.slots_cap = slots_cap; Ln.g_min = g_min;
         if (kind == 3u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs32(d_views, d_wave_map, (uint32_t)wave_map.size(), mx, c.opts.circular != 0, sh, sA); }
-        else if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, d_wave_map, (uint32_t)wave_map.size(), REGS_WAVES, mx, c.opts.circular != 0, sh, sA); }
+        else if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, d_wave_map, (uint32_t)wave_map.size(), c.regs_waves, mx, c.opts.circular != 0, sh, sA); }
         else if (kind == 1u) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, sA);
         else launch_fill(d_views, nj, waves, sh, sA);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[1], sA));
+        Ln.h_submit = host_ms();
         return STITCH_OK;
     };
     auto finish = [&](Launch& Ln) -> int {
         const size_t k0 = Ln.k0, k1 = Ln.k1; const uint32_t nj = Ln.nj; (void)k1;
+        const double h_fin0 = host_ms(); double h_walked = 0; float tr_fill0 = 0, tr_fill1 = 0, tr_walk0 = 0, tr_walk1 = 0;
         std::vector<JobView>& views = Ln.views; std::vector<WalkArgs>& wargs = Ln.wargs; std::vector<size_t>& base = Ln.base;
         JobView* const d_views = Ln.d_views; WalkArgs* const d_wargs = Ln.d_wargs;
         uint32_t G = Ln.G, slots_cap = Ln.slots_cap, kind = Ln.kind; int waves = Ln.waves;
@@ -892,6 +914,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         HIP_TRY(hipEventElapsedTime(&t_start, c.ev[0], ev[0])); HIP_TRY(hipEventElapsedTime(&t_end, c.ev[0], ev[1]));
         { const double a = std::max((double)t_start, covered_until); if ((double)t_end > a) c.tm.fill_ms += (double)t_end - a; covered_until = std::max(covered_until, (double)t_end); }
         HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); c.tm.walk_ms += ms;
+        if (c.knobs.trace) { h_walked = host_ms(); tr_fill0 = t_start; tr_fill1 = t_end; HIP_TRY(hipEventElapsedTime(&tr_walk0, c.ev[0], ev[2])); HIP_TRY(hipEventElapsedTime(&tr_walk1, c.ev[0], ev[3])); }
         if (c.knobs.debug) fprintf(stderr, "[stitch] launch: %u jobs, %u workgroups per read, %d waves, fill %.1f ms, fix-up + walk %.1f ms\n", nj, G, waves, ms_fill, ms);
         if (attempt == 0) { c.tm.launches += 1; c.tm.jobs += nj; }
         if (c.knobs.profile_dump && (kind == 2u || kind == 3u)) {
@@ -1044,6 +1067,8 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         }
         if (int e = flush()) return e;
         c.tm.d2h_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d2h0).count();
+        if (c.knobs.trace) fprintf(stderr, "[trace] launch jobs %zu-%zu slot %d: host start %.1f submit %.1f finish-enter %.1f walked %.1f done %.1f | device fill %.1f-%.1f walk %.1f-%.1f (ms)\n",
+                                   k0, k1, Ln.slot, Ln.h_start, Ln.h_submit, h_fin0, h_walked, host_ms(), tr_fill0, tr_fill1, tr_walk0, tr_walk1);
         return STITCH_OK;
     };
     // the launches, in order; with two windows the next fill is started before the last one is finished
