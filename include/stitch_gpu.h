@@ -101,7 +101,8 @@ typedef struct stitch_timing { double fill_ms, walk_ms, h2d_ms, d2h_ms, host_ms;
                                   threads concurrently with prealign_ms of the chunk before, so the two overlap */;
                                uint32_t fill_kind /* kernel of the last fill launch: 0 generic int32, 1 Local-mode streaming, 2 Local-mode register-resident, 3 register-resident 32-bit (every mode, long reads) */,
                                         wg_per_read /* workgroups that shared one read in that launch */,
-                                        fallbacks /* launches repeated with one workgroup per read after a partner timeout */, pad_;
+                                        fallbacks /* launches repeated with one workgroup per read after a partner timeout */,
+                                        stream_runs /* fill launches whose teams were persistent: each pulled its next read off a queue when one ended (round 4) */;
                                uint64_t clk_shader_cycles, clk_ref_ticks /* register-resident fill only: shader cycles (s_memtime) and 100 MHz ticks
                                   (s_memrealtime) over the column loop of the first read of every launch, summed: cycles / ticks x 100 = MHz */;
                                double fill_kernel_ms /* sum of the fill kernels' own durations (what a profiler lists per dispatch).  fill_ms is the time during

@@ -242,7 +242,7 @@ __device__ __forceinline__ void group_records(Recs& R, const uint32_t g4, const 
 
 // NQ = granule registers per lane: 1 for up to 64 active contigs, 4 for up to 256
 template <int NQ, bool CIRC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS_WAVES_PER_EU, STITCH_REGS_WAVES_PER_EU))) void fill_regs_kernel(const JobView* __restrict__ jobs, FillShared sh, const uint2* __restrict__ wave_map, uint32_t n_waves) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS_WAVES_PER_EU, STITCH_REGS_WAVES_PER_EU))) void fill_regs_kernel(const JobView* __restrict__ jobs, FillShared sh, const uint2* __restrict__ wave_map, uint32_t n_waves, const StreamCtl* __restrict__ qp) {
     // The launch's waves are dealt to the reads' contigs DENSELY: wave w of the grid is entry w of `wave_map` = {read of the launch,
     // active contig of that read}.  A team (the waves of one read) needs nothing of a workgroup - no barrier, no shared LDS, the
     // exchange goes through memory - so its waves may sit in any workgroups; the host keeps the launch within the wave slots of the
@@ -252,7 +252,54 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     if (wv >= n_waves) return;
     const uint2 wm = wave_map[wv];
     // (tell the compiler these are uniform, so that everything read through V is scalar)
-    const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm.x);
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm.x);       // classic launch: the job; persistent teams: the team
+    const uint32_t kmine = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm.y);      // this wave's contig: active contig number
+    const bool streaming = qp != nullptr;           // (the queue's words are read through qp where they are needed: two scalar registers across the column loop, not fifteen)
+    // ---- persistent teams: one round of this loop per read the team aligns (a classic launch leaves after the first) -----------------
+    for (uint32_t seq = 1;; ++seq) {
+    uint32_t job = slot;
+    if (streaming) {
+        const StreamCtl q = *qp;
+        // The team's first wave takes the next job off the queue and announces it in the team's mailbox {round, job}; the others wait for
+        // this round's announcement.  (A team cannot lap itself: a read has at least two columns, and no wave gets past column 2 of a read
+        // without the granules all its team mates wrote AFTER reading this round's mailbox.)
+        const gptr<unsigned long long> mb = as_global(q.mbox) + slot;
+        const int lane0 = threadIdx.x & 63;
+        uint32_t idx = 0xFFFFFFFFu;
+        if (kmine == 0u) {
+            if (lane0 == 0) {
+                if (__hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) idx = atomicAdd(q.next, 1u);
+                if (idx >= q.n_jobs) idx = 0xFFFFFFFFu;
+                __hip_atomic_store(mb, ((unsigned long long)seq << 32) | idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        }
+        else {
+            const uint32_t t0 = (uint32_t)wall_clock64();
+            for (uint32_t spins = 1;; ++spins) {
+                const unsigned long long v = __hip_atomic_load(mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(v >> 32) == seq) { idx = (uint32_t)v; break; }
+                if ((spins & 255u) == 0 && (uint32_t)wall_clock64() - t0 > 400000000u) {      // 4 s: the team's first wave is gone
+                    if (lane0 == 0) __hip_atomic_store(q.h_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        }
+        if (idx == 0xFFFFFFFFu) return;                      // the queue is empty (or the host has called the run off)
+        job = idx;
+        // the job's arena block is the one job - blocks used: wait until the host has walked that read and taken its chains (bounded:
+        // 40 s; the host ends a run that makes no progress earlier and says so through h_abort)
+        {
+            const uint32_t t0 = (uint32_t)wall_clock64();
+            for (uint32_t spins = 1;; ++spins) {
+                if (__hip_atomic_load(q.h_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > job) break;
+                if ((spins & 63u) == 0 && (__hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || (uint32_t)wall_clock64() - t0 > 4000000000u)) return;
+                __builtin_amdgcn_s_sleep(127);
+            }
+        }
+    }
     const JobView& V = jobs[job];
 #ifdef STITCH_EXP_PRIO
     if (job & 1u) __builtin_amdgcn_s_setprio(2);       // experiment: every other read's team has priority on the SIMDs it shares
@@ -263,9 +310,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     uint8_t* const s_wave = s_dyn + (size_t)wave * LDS_PER_WAVE;
 
-    // ---- this wave's contig: active contig number ------------------------------------------------------------------------------------
-    const uint32_t kmine = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm.y);
-    if (kmine >= nact) return;
+    if (kmine >= nact) return;                     // (a padding entry of the wave map)
     const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)V.act[kmine]);
     ContigDesc cd = V.cd[c];
     cd.m = (uint32_t)__builtin_amdgcn_readfirstlane((int)cd.m); cd.roff = (uint32_t)__builtin_amdgcn_readfirstlane((int)cd.roff);
@@ -425,7 +470,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
                     // 4 s at 100 MHz: a partner is not resident — or another wave of the read has said so already (its error word, read
                     // at agent scope: a workgroup that becomes resident late does not wait its own four seconds)
                     const uint32_t e_seen = __builtin_amdgcn_raw_buffer_load_b32(rxc, 0u, 32u * C, AUX_SC1 | AUX_VOLATILE);
-                    if (e_seen != 0u || (uint32_t)wall_clock64() - t0 > 400000000u) { if (lane == 0) *V.err = 1; return; }
+                    if (e_seen != 0u || (uint32_t)wall_clock64() - t0 > 400000000u) {
+                        if (lane == 0) { *V.err = 1; if (streaming) __hip_atomic_store(qp->h_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                        return;
+                    }
                 }
                 __builtin_amdgcn_s_sleep(STITCH_POLL_SLEEP);
             }
@@ -784,6 +832,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
             V.Sn[roff + row] = word_score((int32_t)rec.x); V.SnLen[roff + row] = word_len((int32_t)rec.x); V.Ly[roff + row] = rec.y;
         }
     }
+    if (!streaming) return;
+    // ---- persistent teams: this wave's results are complete.  They are written back beyond this XCD's L2 (the fix-up / walk kernel the
+    // host starts for the read runs on any CU), THEN the wave counts itself in; the wave that completes the count tells the host.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the compiler may drop the wait behind the write-back when it thinks nothing is outstanding)
+    if (lane == 0) {
+        const uint32_t before = atomicAdd(qp->cnt + job, 1u);
+        if (before + 1u == nact) __hip_atomic_store(qp->h_done + job, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    }
 }
 
 uint32_t fill_regs_rows_per_wave() { return 64u * RMAX; }
@@ -802,10 +861,11 @@ int fill_regs_workgroups_per_cu(uint32_t waves) {
     return least;
 }
 // max_nact: the largest number of active contigs of any job of the launch; circular: opts.circular
-void launch_fill_regs(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream) {
+// q == nullptr: a classic launch (wave_map[w].x = the job); else persistent teams that pull jobs off the queue (wave_map[w].x = the team)
+void launch_fill_regs(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, const StreamCtl* q, hipStream_t stream) {
     const dim3 grid((n_waves + waves - 1) / waves), block(waves * 64); const size_t lds = (size_t)waves * LDS_PER_WAVE;
-    if (max_nact <= 64) { if (circular) hipLaunchKernelGGL((fill_regs_kernel<1, true>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); else hipLaunchKernelGGL((fill_regs_kernel<1, false>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); }
-    else { if (circular) hipLaunchKernelGGL((fill_regs_kernel<4, true>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); else hipLaunchKernelGGL((fill_regs_kernel<4, false>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves); }
+    if (max_nact <= 64) { if (circular) hipLaunchKernelGGL((fill_regs_kernel<1, true>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves, q); else hipLaunchKernelGGL((fill_regs_kernel<1, false>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves, q); }
+    else { if (circular) hipLaunchKernelGGL((fill_regs_kernel<4, true>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves, q); else hipLaunchKernelGGL((fill_regs_kernel<4, false>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves, q); }
 }
 
 }  // namespace stitch

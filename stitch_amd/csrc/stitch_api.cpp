@@ -49,13 +49,16 @@ struct FillShared {
     const int32_t* S0; const uint32_t* Slen0; const int32_t* Sn0; const uint8_t* SnSet0; const uint8_t* Smove0;
     const uint32_t* lx0; const JumpBase* base0;
 };
+struct StreamCtl {                      // == fill_common.h (persistent teams of fill_regs.hip)
+    uint32_t* next; uint32_t* cnt; unsigned long long* mbox; uint32_t* h_ready; uint32_t* h_abort; uint32_t* h_done; uint32_t* h_err; uint32_t n_jobs;
+};
 void launch_fill(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillShared& sh, hipStream_t stream);
 void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, uint32_t max_nact_mode1, hipStream_t stream);
 constexpr size_t PIN_BYTES = (size_t)64 << 20;   // pinned staging buffer for result downloads
 constexpr uint32_t TILE_ROWS = 512;   // 64 lanes x 8 rows (Local-mode kernel; the generic one uses 256): contig row blocks are padded to this
 void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, uint32_t slots_cap, const FillShared& sh, hipStream_t stream);
 uint32_t fill_local16_max_slots();
-void launch_fill_regs(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
+void launch_fill_regs(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, const StreamCtl* q /* device copy; nullptr = classic launch */, hipStream_t stream);
 uint32_t fill_regs_rows_per_wave();
 int fill_regs_workgroups_per_cu(uint32_t waves);
 void launch_fill_regs32(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
@@ -93,7 +96,7 @@ struct Knobs {
     size_t array_align = 0, job_align = 0;
     std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
-    int regs_waves = 0, regs_map = 0; bool trace = false;      // (experiments) waves per workgroup of fill_regs.hip, order of its wave map; launch timeline on stderr
+    int regs_waves = 0, regs_map = 0; bool trace = false, no_stream = false; int stream_blocks = 0, stream_teams = 0, stream_range = 0;      // (experiments) waves per workgroup of fill_regs.hip, order of its wave map; launch timeline on stderr
     static Knobs from_env() {
         Knobs k;
         auto num = [](const char* name) -> unsigned long long { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : 0ull; };
@@ -112,6 +115,10 @@ struct Knobs {
         k.array_align = (size_t)num("STITCH_ARRAY_ALIGN"); k.job_align = (size_t)num("STITCH_JOB_ALIGN");
         k.max_waves = (int)num("STITCH_MAX_WAVES"); k.wg_per_read = (int)num("STITCH_WG_PER_READ"); k.tiles_per_wave = (int)num("STITCH_TILES_PER_WAVE");
         k.regs_waves = (int)num("STITCH_REGS_WAVES"); k.regs_map = (int)num("STITCH_REGS_MAP"); k.trace = getenv("STITCH_TRACE") != nullptr;
+        k.no_stream = getenv("STITCH_NO_STREAM") != nullptr;      // launch by launch even where persistent teams apply (A/B runs, tests)
+        k.stream_blocks = (int)num("STITCH_STREAM_BLOCKS");       // (tests) cap on the arena blocks of a persistent-team run
+        k.stream_range = (int)num("STITCH_STREAM_RANGE");         // (experiments) most jobs walked by one fix-up + walk launch
+        k.stream_teams = (int)num("STITCH_STREAM_TEAMS");         // (tests) ... and on its teams, so that small batches queue up behind few teams
         if (const char* e = getenv("STITCH_REGS_MIN_ROWS")) k.regs_min_rows = atol(e);     // (tests: 0 sends every eligible read to fill_regs.hip)
         return k;
     }
@@ -146,6 +153,7 @@ struct stitch_ctx {
     std::vector<stitch_read_result> rr; std::vector<stitch_chain> chains; std::vector<stitch_op> ops;
     uint8_t* pin = nullptr;                       // pinned staging buffer for result downloads (PIN_BYTES)
     uint8_t* pin_h2d = nullptr; size_t pin_h2d_bytes = 0;   // pinned staging of a launch's per-job inputs
+    uint32_t* pin_q = nullptr; size_t pin_q_words = 0;      // persistent teams: the words host and kernel exchange while it runs (pinned, mapped, coherent)
     uint16_t* pin_bands[2] = {nullptr, nullptr}; size_t pin_bands_elems = 0;   // pinned band staging of the pre-alignment pipeline (two chunks)
     std::vector<std::vector<HAln>> job_chains;   // final chains per job (a run of identical reads shares one job)
     std::vector<long> per_read;                  // read -> index into job_chains, -1 = none; for stitch_format_sam
@@ -155,6 +163,7 @@ struct stitch_ctx {
     int regs_wg_per_cu = 0;                      // workgroups of fill_regs.hip one CU holds at once (occupancy query; 0: kernel unusable)
     int regs32_wg_per_cu = 0;                    // ... of fill_regs32.hip (one: a wave takes a SIMD's whole register file)
     bool tm_fast = false;                        // last run_jobs used the Local-mode 16-bit kernel
+    bool in_stream_fallback = false;             // run_jobs_streaming is on the stack (its fallback goes launch by launch)
     size_t mem_limit = 0;                        // optional cap on arena bytes (STITCH_ARENA_BYTES), for tests
     // banded pre-alignment filter (prealign.h): host copies of the contig strands, their k-mer indexes, device scratch
     std::vector<uint8_t> h_xseq; std::vector<Strand> strands; KmerIndex kidx;
@@ -246,6 +255,7 @@ int stitch_index_deserialize(const void* buf, size_t len, stitch_index** out) {
 }
 
 void stitch_ctx_destroy(stitch_ctx* c) {
+    if (c && c->pin_q) { (void)hipHostFree(c->pin_q); c->pin_q = nullptr; }
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_xseq, c->d_S0, c->d_Slen0, c->d_Sn0, c->d_SnSet0, c->d_Smove0, c->d_Imove0, c->d_lx0, c->d_base0, c->arena_raw, c->pre_buf};
@@ -495,6 +505,90 @@ int pick_waves(const stitch_ctx& c, uint32_t nact, int maxw) {          // fewes
     return best_w;
 }
 
+// Chains of the jobs [k0, k0 + nj) after their fix-up + walk: headers first, then the operation lists, both batched through a pinned
+// staging buffer (one synchronous pageable copy per chain costs ~0.15 ms each; --suboptimal yields hundreds of chains per read).
+// blocks[q] = the arena block of job k0 + q, d_views = the launch's job table (entry q = job k0 + q).  A chain whose operations did not
+// fit its buffer (only possible with free gaps / jumps) is walked again into an exact-size buffer; that path allocates and frees device
+// memory, which waits for every kernel on the device: with persistent teams running (allow_rewalk == false) the caller is told
+// instead (return value 1) and repeats the read on the classic path.
+int download_chains(stitch_ctx& c, hipStream_t sB, std::vector<Job>& jobs, const std::vector<JobLayout>& lay, size_t k0, uint32_t nj,
+                    const std::vector<uint8_t*>& blocks, JobView* d_views, bool allow_rewalk) {
+        auto t_d2h0 = std::chrono::steady_clock::now();
+        if (!c.pin) { HIP_TRY(hipHostMalloc((void**)&c.pin, PIN_BYTES, hipHostMallocDefault)); }
+        struct Pending { void* dst; const uint8_t* src; size_t bytes; };
+        std::vector<Pending> pend;
+        auto flush = [&]() -> int {
+            size_t i = 0;
+            while (i < pend.size()) {
+                if (pend[i].bytes > PIN_BYTES) {
+                    if (!allow_rewalk) { HIP_TRY(hipMemcpyAsync(pend[i].dst, pend[i].src, pend[i].bytes, hipMemcpyDeviceToHost, sB)); HIP_TRY(hipStreamSynchronize(sB)); }
+                    else HIP_TRY(hipMemcpy(pend[i].dst, pend[i].src, pend[i].bytes, hipMemcpyDeviceToHost));
+                    ++i; continue;
+                }
+                size_t used = 0, j = i;
+                while (j < pend.size() && used + pend[j].bytes <= PIN_BYTES) {
+                    HIP_TRY(hipMemcpyAsync(c.pin + used, pend[j].src, pend[j].bytes, hipMemcpyDeviceToHost, sB));
+                    used += align_up(pend[j].bytes, 64); ++j;
+                }
+                HIP_TRY(hipStreamSynchronize(sB));
+                used = 0;
+                for (size_t k = i; k < j; ++k) { memcpy(pend[k].dst, c.pin + used, pend[k].bytes); used += align_up(pend[k].bytes, 64); }
+                i = j;
+            }
+            pend.clear();
+            return STITCH_OK;
+        };
+        std::vector<std::vector<ChainHdr>> hdrs(nj);
+        for (uint32_t q = 0; q < nj; ++q) {
+            const JobLayout& L = lay[k0 + q];
+            hdrs[q].resize(L.slots);
+            pend.push_back({hdrs[q].data(), blocks[q] + L.off_hdr, sizeof(ChainHdr) * (size_t)L.slots});
+        }
+        if (int e = flush()) return e;
+        for (uint32_t q = 0; q < nj; ++q) {
+            Job& jb = jobs[k0 + q]; const JobLayout& L = lay[k0 + q]; uint8_t* B = blocks[q];
+            jb.chains.assign(L.slots, HAln()); jb.status.assign(L.slots, 0);
+            for (uint32_t s = 0; s < L.slots; ++s) {
+                ChainHdr H = hdrs[q][s];
+                const uint8_t* ops_src = B + L.off_ops + sizeof(OpRec) * (size_t)s * L.ops_cap;
+                uint8_t* big = nullptr;
+                if (H.status == 2) {
+                    if (!allow_rewalk) return 1;
+                    // more operations than the default buffer holds (only with free gaps/jumps): walk this chain again
+                    // into a buffer of the size the first walk counted; the fix-ups must not run twice
+                    struct Retry { ChainHdr h; WalkArgs a; };
+                    const size_t ops_bytes = sizeof(OpRec) * (size_t)H.n_ops;
+                    HIP_TRY(hipMalloc((void**)&big, align_up(sizeof(Retry), 256) + ops_bytes));
+                    Retry rt{}; rt.a.hdr = (ChainHdr*)big; rt.a.ops = (OpRec*)(big + align_up(sizeof(Retry), 256)); rt.a.ops_cap = H.n_ops;
+                    rt.a.mode = 2; rt.a.from = H.end_contig_idx; rt.a.skip_fixup = 1;
+                    HIP_TRY(hipMemcpy(big, &rt, sizeof(Retry), hipMemcpyHostToDevice));
+                    launch_fixup_walk(d_views + q, (const WalkArgs*)(big + offsetof(Retry, a)), 1, 0, sB);
+                    HIP_TRY(hipStreamSynchronize(sB));
+                    HIP_TRY(hipMemcpy(&H, big, sizeof(ChainHdr), hipMemcpyDeviceToHost));
+                    ops_src = big + align_up(sizeof(Retry), 256);
+                }
+                jb.status[s] = H.status;
+                if (H.status == 4) { if (big) (void)hipFree(big); return fail(STITCH_EINVAL, "end-of-read jump into a shorter contig: the reference indexes its traceback matrix out of range here (traceback/mod.rs:329-338); result undefined"); }
+                if (H.status >= 2) { if (big) (void)hipFree(big); return fail(STITCH_EINTERNAL, "traceback failed on the device (status " + std::to_string(H.status) + ")"); }
+                if (H.status == 1) { if (big) (void)hipFree(big); continue; }
+                if ((size_t)H.n_ops > (big ? (size_t)H.n_ops : (size_t)L.ops_cap)) return fail(STITCH_EINTERNAL, "chain header reports more operations than its buffer holds");
+                HAln& a = jb.chains[s];
+                a.score = H.score; a.xstart = H.xstart; a.xend = H.xend; a.ystart = H.ystart; a.yend = H.yend; a.xlen = H.xlen; a.ylen = H.ylen;
+                a.start_contig_idx = H.start_contig_idx; a.end_contig_idx = H.end_contig_idx; a.length = H.length;
+                a.ops.resize(H.n_ops);
+                static_assert(sizeof(OpRec) == sizeof(stitch_op), "op layout");
+                if (H.n_ops) {
+                    if (big) { HIP_TRY(hipMemcpy(a.ops.data(), ops_src, sizeof(OpRec) * (size_t)H.n_ops, hipMemcpyDeviceToHost)); }
+                    else pend.push_back({a.ops.data(), ops_src, sizeof(OpRec) * (size_t)H.n_ops});
+                }
+                if (big) (void)hipFree(big);
+            }
+        }
+        if (int e = flush()) return e;
+        c.tm.d2h_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d2h0).count();
+        return STITCH_OK;
+}
+
 static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs);
 
 // Jobs of one launch run side by side until the longest is done, so launches are formed from jobs of similar size: the list
@@ -514,8 +608,246 @@ int run_jobs(stitch_ctx& c, std::vector<Job>& jobs) {
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent teams (round 4).  A classic launch of fill_regs.hip holds as many reads as fill the chip's wave slots and ends with its
+// SLOWEST read (reads differ by 20-30 %: DESIGN.md 4); with two launches in flight the next launch takes the slots finished reads
+// free, but launch k + 2 still waits for all of launch k.  Here ONE launch per call keeps T teams (T x W waves = the chip's wave
+// slots, W = active contigs per read) resident for the whole batch: a team that ends a read pulls the next one off a queue in device
+// memory.  The arena is cut into B blocks, job i uses block i mod B; the host watches the jobs' completion words (pinned host memory),
+// runs fix-up + walk + downloads for finished jobs on the second stream and then lets job i + B start (h_ready).  Nothing the
+// running kernel READS is written by the host after the launch except those pinned words: every job's read, contig tables and
+// exchange granules are uploaded / cleared up front in a region of their own, and the block arrays are all written by the fill before
+// it reads them.  Applies when every job takes the register-resident kernel with the same number of active contigs (cfg2, cfg4, cfg5;
+// not the filtered reads of cfg3, whose teams differ in size) and there are more jobs than teams.
+// Returns STITCH_OK with *handled = true when the jobs were run here; *handled = false (and STITCH_OK) when the classic path should.
+static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handled) {
+    *handled = false;
+    const size_t N = jobs.size();
+    const Knobs& kn = c.knobs;
+    if (kn.no_stream || kn.debug || kn.profile_dump || kn.fill_only || !kn.dump_dir.empty() || kn.no_pipeline || kn.fail_first_attempt || kn.force_regs32 || kn.regs_map) return STITCH_OK;
+    if (N < 2 || c.regs_wg_per_cu <= 0) return STITCH_OK;
+    const uint32_t W = (uint32_t)jobs[0].act.size();
+    for (const Job& jb : jobs) if (jb.act.size() != W || jb.y.size() < 2 || regs_plan(c, jb) == 0) return STITCH_OK;
+    const size_t slots = (size_t)c.n_cus * (size_t)c.regs_wg_per_cu * c.regs_waves;
+    size_t T = slots / W;
+    if (kn.stream_teams > 0) T = std::min<size_t>(T, (size_t)kn.stream_teams);
+    if (T < 1 || N <= T) return STITCH_OK;            // (one classic launch holds them all)
+    HIP_TRY(hipSetDevice(c.device));
+    std::vector<JobLayout> lay(N);
+    size_t max_job = 0, in_total = 0;
+    std::vector<size_t> in_at(N + 1, 0);
+    for (size_t k = 0; k < N; ++k) { lay[k] = layout_job(c, jobs[k]); max_job = std::max(max_job, lay[k].bytes); in_at[k + 1] = in_at[k] + align_up(lay[k].off_hdr - lay[k].off_y, 256); }
+    in_total = in_at[N];
+    const size_t xbytes = align_up(32ull * c.C + 4096, 256);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = (size_t)(std::min(free_b + c.arena_bytes, total_b) * 0.90);
+    if (c.mem_limit) budget = std::min(budget, c.mem_limit);
+    // behind the blocks: job table, walk arguments, the jobs' inputs, their exchange granules + error words, wave counters, mailboxes, queue head, wave map, the control block
+    const size_t fixed = align_up(sizeof(JobView) * N, 256) + align_up(sizeof(WalkArgs) * N, 256) + in_total + xbytes * N + align_up(4 * N, 256) + align_up(8 * T, 256) + 256 +
+                         align_up(sizeof(uint2) * T * W + 64, 256) + 256 + ((size_t)1 << 20);
+    // blocks at multiples of a large power of two, like the classic windows (the jobs' streams want to be congruent)
+    size_t a_pick = 0, stride = 0, B = 0;
+    for (size_t a = (size_t)1 << 30; a >= 256; a >>= 1) {
+        if (a > max_job && a > 256) continue;
+        const size_t st = align_up(max_job, a);
+        if (a > 256 && st % (4 * a) == 0) continue;
+        if (budget < fixed + a + st) { if (a == 256) break; continue; }
+        size_t b = std::min(N, (budget - fixed - a) / st);
+        if (kn.stream_blocks > 0) b = std::min<size_t>(b, (size_t)kn.stream_blocks);
+        if (b >= std::min(N, T + 2) || a == 256) { a_pick = a; stride = st; B = b; break; }
+    }
+    if (B < 2) return STITCH_OK;
+    if (B < T) T = B;                                  // (fewer blocks than the chip holds teams: as many teams as blocks)
+    if (N <= T) return STITCH_OK;
+    const size_t need = B * stride + fixed + a_pick;
+    auto arena_fits = [&]() { return c.arena && align_up((size_t)(uintptr_t)c.arena, a_pick) + B * stride + fixed <= (size_t)(uintptr_t)c.arena + c.arena_bytes; };
+    if (!arena_fits()) {
+        if (c.arena) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c.arena_raw)); c.arena_raw = nullptr; c.arena = nullptr; c.arena_bytes = 0; }
+        if (hipMalloc((void**)&c.arena_raw, need + a_pick) != hipSuccess) { (void)hipGetLastError(); c.arena_raw = nullptr; return STITCH_OK; }      // (the classic path sizes its own arena)
+        c.arena = (uint8_t*)align_up((size_t)(uintptr_t)c.arena_raw, std::max<size_t>(a_pick, 256)); c.arena_bytes = need + a_pick - (size_t)(c.arena - c.arena_raw);
+    }
+    uint8_t* const blocks0 = (uint8_t*)align_up((size_t)(uintptr_t)c.arena, a_pick);
+    uint8_t* tail = blocks0 + B * stride;
+    auto carve = [&](size_t bytes) { uint8_t* at = tail; tail += align_up(bytes, 256); return at; };
+    JobView* const d_views = (JobView*)carve(sizeof(JobView) * N);
+    WalkArgs* const d_wargs = (WalkArgs*)carve(sizeof(WalkArgs) * N);
+    uint8_t* const d_in = carve(in_total);
+    uint8_t* const d_zero = tail;                                   // one clear: granules + error words, wave counters, mailboxes, queue head
+    uint8_t* const d_x = carve(xbytes * N);
+    uint32_t* const d_cnt = (uint32_t*)carve(4 * N);
+    unsigned long long* const d_mbox = (unsigned long long*)carve(8 * T);
+    uint32_t* const d_next = (uint32_t*)carve(256);
+    const size_t zero_bytes = (size_t)(tail - d_zero);
+    uint2* const d_wave_map = (uint2*)carve(sizeof(uint2) * T * W + 64);
+    StreamCtl* const d_ctl = (StreamCtl*)carve(256);
+    if ((size_t)(tail - c.arena) > c.arena_bytes) return fail(STITCH_EINTERNAL, "arena overflow (persistent teams)");
+    // pinned words: [0] ready, [16] abort, [32] err (a cache line each), [64 ..] done[N]
+    if (c.pin_q_words < 64 + N) {
+        if (c.pin_q) { (void)hipHostFree(c.pin_q); c.pin_q = nullptr; c.pin_q_words = 0; }
+        const size_t words = std::max<size_t>(4096, (64 + N) * 2);
+        HIP_TRY(hipHostMalloc((void**)&c.pin_q, 4 * words, hipHostMallocMapped | hipHostMallocCoherent));
+        c.pin_q_words = words;
+    }
+    volatile uint32_t* const hq = c.pin_q;
+    for (size_t k = 0; k < 64 + N; ++k) hq[k] = 0u;
+    if (!c.pin) { HIP_TRY(hipHostMalloc((void**)&c.pin, PIN_BYTES, hipHostMallocDefault)); }
+    if (in_total > c.pin_h2d_bytes) {
+        if (c.pin_h2d) { (void)hipHostFree(c.pin_h2d); c.pin_h2d = nullptr; c.pin_h2d_bytes = 0; }
+        const size_t want_b = std::max<size_t>(in_total * 3 / 2, (size_t)1 << 20);
+        HIP_TRY(hipHostMalloc((void**)&c.pin_h2d, want_b, hipHostMallocDefault));
+        c.pin_h2d_bytes = want_b;
+    }
+    hipStream_t const sA = c.stream, sB = c.stream2;
+    FillShared sh{c.d_S0, c.d_Slen0, c.d_Sn0, c.d_SnSet0, c.d_Smove0, c.d_lx0, c.d_base0};
+    c.tm_fast = true;
+    const auto t_h2d0 = std::chrono::steady_clock::now();
+    std::vector<JobView> views(N); std::vector<WalkArgs> wargs(N);
+    auto block_of = [&](size_t k) { return blocks0 + (k % B) * stride; };
+    for (size_t k = 0; k < N; ++k) {
+        const Job& jb = jobs[k]; const JobLayout& L = lay[k];
+        uint8_t* const Bk = block_of(k); uint8_t* const In = d_in + in_at[k]; uint8_t* const X = d_x + xbytes * k;
+        std::vector<ContigDesc> cd(c.C); std::vector<int32_t> opp(c.C, -1); std::vector<uint8_t> isact(c.C, 0);
+        for (uint32_t a : jb.act) isact[a] = 1;
+        uint32_t roff = 0;
+        for (uint32_t a = 0; a < c.C; ++a) {
+            ContigDesc d{}; d.m = c.al[a].m; d.troff = c.al[a].troff; d.seqoff = c.al[a].seqoff; d.target = c.al[a].target; d.opp = c.al[a].opp;
+            d.roff = 0;
+            { const uint32_t ngr = (d.m + 3) / 4, gq = ngr / 64; d.inv_big = tb_div_magic(4 * (gq + 1)); d.inv_small = tb_div_magic(4 * gq); }
+            if (isact[a]) { d.roff = roff; roff += (d.m + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS; }
+            cd[a] = d;
+            if (isact[a] && c.al[a].opp >= 0 && isact[c.al[a].opp]) opp[a] = c.al[a].opp;      // (only within the current subset: multi_contig_aligner.rs:241-262)
+        }
+        uint8_t* stg = c.pin_h2d + in_at[k];
+        memcpy(stg, jb.y.data(), L.n);
+        memcpy(stg + (L.off_act - L.off_y), jb.act.data(), 4ull * L.nact);
+        memcpy(stg + (L.off_opp - L.off_y), opp.data(), 4ull * c.C);
+        memcpy(stg + (L.off_cd - L.off_y), cd.data(), sizeof(ContigDesc) * (size_t)c.C);
+        JobView& V = views[k];
+        V.tb_keyfmt = 2u; V.yrec_global = jb.mode == 0 ? 1u : 0u;
+        V.P = c.P; V.n = L.n; V.C = c.C; V.nact = L.nact; V.Rtot = L.Rj;
+        V.y = In; V.act = (const uint32_t*)(In + (L.off_act - L.off_y)); V.opp_act = (const int32_t*)(In + (L.off_opp - L.off_y)); V.cd = (const ContigDesc*)(In + (L.off_cd - L.off_y));
+        V.xseq = c.d_xseq;
+        V.S = (int32_t*)(Bk + L.off_S); V.Slen = (uint32_t*)(Bk + L.off_Slen); V.D = (int32_t*)(Bk + L.off_D); V.Dlen = (uint32_t*)(Bk + L.off_Dlen);
+        V.st16 = (uint32_t*)(Bk + L.off_st16);
+        V.xchg = (unsigned long long*)X; V.err = (uint32_t*)(X + 32ull * c.C);
+        V.Sn = (int32_t*)(Bk + L.off_Sn); V.SnLen = (uint32_t*)(Bk + L.off_SnLen); V.Ly = (uint32_t*)(Bk + L.off_Ly);
+        V.tb = Bk + L.off_tb; V.Lx = (uint32_t*)(Bk + L.off_Lx); V.jt_idx = (uint32_t*)(Bk + L.off_jti); V.jt_from = (uint32_t*)(Bk + L.off_jtf);
+        V.Ival = (int32_t*)(Bk + L.off_Ival); V.Ilen = (uint32_t*)(Bk + L.off_Ilen); V.SmoveF = Bk + L.off_SmoveF;
+        V.SidxF = (uint32_t*)(Bk + L.off_SidxF); V.SfromF = (uint32_t*)(Bk + L.off_SfromF); V.ImoveF = Bk + L.off_ImoveF;
+        V.Smove0 = c.d_Smove0; V.Imove0 = c.d_Imove0; V.Slen0 = c.d_Slen0;
+        V.Sm = (int32_t*)(Bk + L.off_Sm); V.Lm = (uint32_t*)(Bk + L.off_Lm);
+        WalkArgs& A = wargs[k]; A.hdr = (ChainHdr*)(Bk + L.off_hdr); A.ops = (OpRec*)(Bk + L.off_ops); A.ops_cap = L.ops_cap; A.mode = jb.mode; A.from = jb.from; A.skip_fixup = 0;
+        c.tm.cells += (uint64_t)L.n * [&] { uint64_t s2 = 0; for (uint32_t a : jb.act) s2 += c.al[a].m; return s2; }();
+    }
+    std::vector<uint2> wave_map; wave_map.reserve(T * W);
+    for (uint32_t t = 0; t < (uint32_t)T; ++t) for (uint32_t k = 0; k < W; ++k) wave_map.push_back(make_uint2(t, k));
+    StreamCtl ctl{}; ctl.next = d_next; ctl.cnt = d_cnt; ctl.mbox = d_mbox; ctl.n_jobs = (uint32_t)N;
+    ctl.h_ready = c.pin_q + 0; ctl.h_abort = c.pin_q + 16; ctl.h_err = c.pin_q + 32; ctl.h_done = c.pin_q + 64;
+    HIP_TRY(hipMemcpyAsync(d_in, c.pin_h2d, in_total, hipMemcpyHostToDevice, sB));
+    HIP_TRY(hipMemsetAsync(d_zero, 0, zero_bytes, sB));
+    HIP_TRY(hipMemcpyAsync(d_views, views.data(), sizeof(JobView) * N, hipMemcpyHostToDevice, sB));
+    HIP_TRY(hipMemcpyAsync(d_wargs, wargs.data(), sizeof(WalkArgs) * N, hipMemcpyHostToDevice, sB));
+    HIP_TRY(hipMemcpyAsync(d_wave_map, wave_map.data(), sizeof(uint2) * wave_map.size(), hipMemcpyHostToDevice, sB));
+    HIP_TRY(hipMemcpyAsync(d_ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, sB));
+    HIP_TRY(hipStreamSynchronize(sB));
+    c.tm.h2d_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h2d0).count();
+    hq[0] = (uint32_t)std::min(N, B);                  // the first B jobs find their blocks free
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    hipEvent_t* const ev = c.evp[0];
+    HIP_TRY(hipEventRecord(ev[0], sA));
+    launch_fill_regs(d_views, d_wave_map, (uint32_t)wave_map.size(), c.regs_waves, W, c.opts.circular != 0, sh, d_ctl, sA);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[1], sA));
+    c.tm.fill_kind = 2u; c.tm.wg_per_read = (W + c.regs_waves - 1) / c.regs_waves; c.tm_wg_per_read = c.tm.wg_per_read;
+    if (kn.trace) fprintf(stderr, "[trace] persistent teams: %zu jobs, %zu teams of %u waves, %zu blocks of %zu bytes\n", N, T, W, B, stride);
+
+    // ---- the host's loop: finished jobs, in order, get their fix-up + walk and downloads on sB; then the job B further on may start ----
+    size_t fin = 0;
+    bool broken = false; int rc_fatal = STITCH_OK;
+    auto t_last = std::chrono::steady_clock::now();
+    const auto t_run0 = t_last;
+    while (fin < N) {
+        size_t b = fin;
+        // At most eight jobs per fix-up + walk launch.  The fill's teams never leave, so a walk's workgroups only ever get the few wave slots
+        // the fill left free, and the dispatcher deals a grid's workgroups to the XCDs (and their shader engines) in a fixed rotation: a
+        // workgroup whose turn falls on a full engine waits there although another has room.  Measured (gpurun_out/r4b, r4c): walks of up
+        // to six workgroups beside 2000 resident fill waves take their 7-9 ms, walks of 14 or more never start until fill waves leave.
+        const size_t range_cap = kn.stream_range > 0 ? (size_t)kn.stream_range : 8;
+        while (b < N && hq[64 + b] != 0u && b - fin < range_cap) ++b;
+        if (b == fin) {
+            if (hq[32] != 0u) { broken = true; break; }                            // a wave gave up waiting (partner not resident, lost mailbox)
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count() > 30.0 + 1e-3 * (double)lay[fin].n) { broken = true; break; }      // (no read takes that long)
+            std::this_thread::sleep_for(std::chrono::microseconds(40));
+            continue;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const uint32_t nj = (uint32_t)(b - fin);
+        uint32_t max_nact_mode1 = 0;
+        for (size_t k = fin; k < b; ++k) if (jobs[k].mode == 1) max_nact_mode1 = std::max(max_nact_mode1, lay[k].nact);
+        HIP_TRY(hipEventRecord(ev[2], sB));
+        launch_fixup_walk(d_views + fin, d_wargs + fin, nj, max_nact_mode1, sB);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev[3], sB));
+        const double tr0 = kn.trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count() : 0.0;
+        if (kn.trace) HIP_TRY(hipStreamSynchronize(sB));
+        const double tr1 = kn.trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count() : 0.0;
+        for (uint32_t q2 = 0; q2 < nj; ++q2) HIP_TRY(hipMemcpyAsync(c.pin + 4ull * q2, views[fin + q2].err, 4, hipMemcpyDeviceToHost, sB));
+        HIP_TRY(hipStreamSynchronize(sB));
+        const double tr2 = kn.trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count() : 0.0;
+        { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); c.tm.walk_ms += ms; if (kn.trace) fprintf(stderr, "[trace] jobs %zu-%zu: walk submitted %.1f, done %.1f (kernel %.2f ms), error words %.1f\n", fin, b, tr0, tr1, ms, tr2); }
+        for (uint32_t q2 = 0; q2 < nj; ++q2) {
+            uint32_t e = 0; memcpy(&e, c.pin + 4ull * q2, 4);
+            if ((e & 0xFFu) == 2u) { rc_fatal = fail(STITCH_EINTERNAL, "fill kernel bounds check failed, code " + std::to_string(e >> 8)); broken = true; }
+            else if (e) broken = true;
+        }
+        if (broken) break;
+        std::vector<uint8_t*> blk(nj);
+        for (uint32_t q2 = 0; q2 < nj; ++q2) blk[q2] = block_of(fin + q2);
+        const int rd = download_chains(c, sB, jobs, lay, fin, nj, blk, d_views + fin, false);
+        if (rd == 1) { broken = true; break; }           // a chain wants the exact-size re-walk (device-synchronising): the classic path does it
+        if (rd) { rc_fatal = rd; broken = true; break; }
+        if (kn.trace) fprintf(stderr, "[trace] jobs %zu-%zu walked and downloaded at %.1f ms\n", fin, b, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count());
+        fin = b;
+        std::atomic_thread_fence(std::memory_order_release);
+        hq[0] = (uint32_t)std::min(N, fin + B);
+        t_last = std::chrono::steady_clock::now();
+    }
+    if (broken) { hq[16] = 1u; std::atomic_thread_fence(std::memory_order_seq_cst); }
+    HIP_TRY(hipStreamSynchronize(sA));                  // (every team leaves once the queue is empty or called off; every wait in the kernel is bounded)
+    { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); c.tm.fill_ms += ms; c.tm.fill_kernel_ms += ms; }
+    c.tm.launches += 1; c.tm.jobs += (uint32_t)fin; c.tm.stream_runs += 1;
+    {
+        HIP_TRY(hipMemcpyAsync(c.pin, (const uint8_t*)views[0].err + ERR_CLOCK_OFF, 16, hipMemcpyDeviceToHost, sB));
+        HIP_TRY(hipStreamSynchronize(sB));
+        unsigned long long ck[2]; memcpy(ck, c.pin, 16);
+        c.tm.clk_shader_cycles += ck[0]; c.tm.clk_ref_ticks += ck[1];
+    }
+    if (rc_fatal) return rc_fatal;
+    if (broken) {
+        // the run was called off (a partner that was not resident, a chain beyond its buffer): the jobs that are not finished run launch
+        // by launch on the classic path, which has the fallback kernels
+        c.tm.fallbacks += 1;
+        std::vector<Job> rest; rest.reserve(N - fin);
+        for (size_t k = fin; k < N; ++k) rest.push_back(std::move(jobs[k]));
+        for (const Job& jb : rest) { uint64_t rows = 0; for (uint32_t a : jb.act) rows += c.al[a].m; c.tm.cells -= (uint64_t)jb.y.size() * rows; }      // (counted again below)
+        const int rc = run_jobs_in_order(c, rest);
+        for (size_t k = fin; k < N; ++k) jobs[k] = std::move(rest[k - fin]);
+        if (rc) return rc;
+    }
+    *handled = true;
+    return STITCH_OK;
+}
+
 static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     if (jobs.empty()) return STITCH_OK;
+    if (!c.in_stream_fallback) {
+        bool handled = false;
+        c.in_stream_fallback = true;                  // (the persistent-team run hands what it could not finish to this function)
+        const int rc = run_jobs_streaming(c, jobs, &handled);
+        c.in_stream_fallback = false;
+        if (rc || handled) return rc;
+    }
     HIP_TRY(hipSetDevice(c.device));
     std::vector<JobLayout> lay(jobs.size());
     size_t max_job = 0;
@@ -844,7 +1176,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         const uint32_t kind = regs_G ? 2u : regs32_G ? 3u : fast ? 1u : 0u;
         Ln.G = G; Ln.kind = kind; Ln.waves = waves; Ln.slots_cap = slots_cap; Ln.g_min = g_min;
         if (kind == 3u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs32(d_views, d_wave_map, (uint32_t)wave_map.size(), mx, c.opts.circular != 0, sh, sA); }
-        else if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, d_wave_map, (uint32_t)wave_map.size(), c.regs_waves, mx, c.opts.circular != 0, sh, sA); }
+        else if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, d_wave_map, (uint32_t)wave_map.size(), c.regs_waves, mx, c.opts.circular != 0, sh, nullptr, sA); }
         else if (kind == 1u) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, sA);
         else launch_fill(d_views, nj, waves, sh, sA);
         HIP_TRY(hipGetLastError());
@@ -997,76 +1329,11 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
 
 
         if (c.knobs.fill_only) return STITCH_OK;
-        // download chains: headers first, then the operation lists, both batched through a pinned staging buffer (one
-        // synchronous pageable copy per chain costs ~0.15 ms each; --suboptimal yields hundreds of chains per read)
-        auto t_d2h0 = std::chrono::steady_clock::now();
-        if (!c.pin) { HIP_TRY(hipHostMalloc((void**)&c.pin, PIN_BYTES, hipHostMallocDefault)); }
-        struct Pending { void* dst; const uint8_t* src; size_t bytes; };
-        std::vector<Pending> pend;
-        auto flush = [&]() -> int {
-            size_t i = 0;
-            while (i < pend.size()) {
-                if (pend[i].bytes > PIN_BYTES) { HIP_TRY(hipMemcpy(pend[i].dst, pend[i].src, pend[i].bytes, hipMemcpyDeviceToHost)); ++i; continue; }
-                size_t used = 0, j = i;
-                while (j < pend.size() && used + pend[j].bytes <= PIN_BYTES) {
-                    HIP_TRY(hipMemcpyAsync(c.pin + used, pend[j].src, pend[j].bytes, hipMemcpyDeviceToHost, sB));
-                    used += align_up(pend[j].bytes, 64); ++j;
-                }
-                HIP_TRY(hipStreamSynchronize(sB));
-                used = 0;
-                for (size_t k = i; k < j; ++k) { memcpy(pend[k].dst, c.pin + used, pend[k].bytes); used += align_up(pend[k].bytes, 64); }
-                i = j;
-            }
-            pend.clear();
-            return STITCH_OK;
-        };
-        std::vector<std::vector<ChainHdr>> hdrs(nj);
-        for (uint32_t q = 0; q < nj; ++q) {
-            const JobLayout& L = lay[k0 + q];
-            hdrs[q].resize(L.slots);
-            pend.push_back({hdrs[q].data(), c.arena + base[q] + L.off_hdr, sizeof(ChainHdr) * (size_t)L.slots});
+        {
+            std::vector<uint8_t*> blocks(nj);
+            for (uint32_t q = 0; q < nj; ++q) blocks[q] = c.arena + base[q];
+            if (int e = download_chains(c, sB, jobs, lay, k0, nj, blocks, d_views, true)) return e;
         }
-        if (int e = flush()) return e;
-        for (uint32_t q = 0; q < nj; ++q) {
-            Job& jb = jobs[k0 + q]; const JobLayout& L = lay[k0 + q]; uint8_t* B = c.arena + base[q];
-            jb.chains.assign(L.slots, HAln()); jb.status.assign(L.slots, 0);
-            for (uint32_t s = 0; s < L.slots; ++s) {
-                ChainHdr H = hdrs[q][s];
-                const uint8_t* ops_src = B + L.off_ops + sizeof(OpRec) * (size_t)s * L.ops_cap;
-                uint8_t* big = nullptr;
-                if (H.status == 2) {
-                    // more operations than the default buffer holds (only with free gaps/jumps): walk this chain again
-                    // into a buffer of the size the first walk counted; the fix-ups must not run twice
-                    struct Retry { ChainHdr h; WalkArgs a; };
-                    const size_t ops_bytes = sizeof(OpRec) * (size_t)H.n_ops;
-                    HIP_TRY(hipMalloc((void**)&big, align_up(sizeof(Retry), 256) + ops_bytes));
-                    Retry rt{}; rt.a.hdr = (ChainHdr*)big; rt.a.ops = (OpRec*)(big + align_up(sizeof(Retry), 256)); rt.a.ops_cap = H.n_ops;
-                    rt.a.mode = 2; rt.a.from = H.end_contig_idx; rt.a.skip_fixup = 1;
-                    HIP_TRY(hipMemcpy(big, &rt, sizeof(Retry), hipMemcpyHostToDevice));
-                    launch_fixup_walk(d_views + q, (const WalkArgs*)(big + offsetof(Retry, a)), 1, 0, sB);
-                    HIP_TRY(hipStreamSynchronize(sB));
-                    HIP_TRY(hipMemcpy(&H, big, sizeof(ChainHdr), hipMemcpyDeviceToHost));
-                    ops_src = big + align_up(sizeof(Retry), 256);
-                }
-                jb.status[s] = H.status;
-                if (H.status == 4) { if (big) (void)hipFree(big); return fail(STITCH_EINVAL, "end-of-read jump into a shorter contig: the reference indexes its traceback matrix out of range here (traceback/mod.rs:329-338); result undefined"); }
-                if (H.status >= 2) { if (big) (void)hipFree(big); return fail(STITCH_EINTERNAL, "traceback failed on the device (status " + std::to_string(H.status) + ")"); }
-                if (H.status == 1) { if (big) (void)hipFree(big); continue; }
-                if ((size_t)H.n_ops > (big ? (size_t)H.n_ops : (size_t)L.ops_cap)) return fail(STITCH_EINTERNAL, "chain header reports more operations than its buffer holds");
-                HAln& a = jb.chains[s];
-                a.score = H.score; a.xstart = H.xstart; a.xend = H.xend; a.ystart = H.ystart; a.yend = H.yend; a.xlen = H.xlen; a.ylen = H.ylen;
-                a.start_contig_idx = H.start_contig_idx; a.end_contig_idx = H.end_contig_idx; a.length = H.length;
-                a.ops.resize(H.n_ops);
-                static_assert(sizeof(OpRec) == sizeof(stitch_op), "op layout");
-                if (H.n_ops) {
-                    if (big) { HIP_TRY(hipMemcpy(a.ops.data(), ops_src, sizeof(OpRec) * (size_t)H.n_ops, hipMemcpyDeviceToHost)); }
-                    else pend.push_back({a.ops.data(), ops_src, sizeof(OpRec) * (size_t)H.n_ops});
-                }
-                if (big) (void)hipFree(big);
-            }
-        }
-        if (int e = flush()) return e;
-        c.tm.d2h_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d2h0).count();
         if (c.knobs.trace) fprintf(stderr, "[trace] launch jobs %zu-%zu slot %d: host start %.1f submit %.1f finish-enter %.1f walked %.1f done %.1f | device fill %.1f-%.1f walk %.1f-%.1f (ms)\n",
                                    k0, k1, Ln.slot, Ln.h_start, Ln.h_submit, h_fin0, h_walked, host_ms(), tr_fill0, tr_fill1, tr_walk0, tr_walk1);
         return STITCH_OK;
