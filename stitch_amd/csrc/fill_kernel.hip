@@ -246,41 +246,13 @@ void launch_fill(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillSh
 // fix-up of one contig each (single_contig_aligner.rs:453-555), then lanes walk (traceback/mod.rs:219-373).
 // mode: 0 = traceback (best end contig), 1 = one chain per active contig (traceback_all candidates, chosen among
 // on the host in the reference's order), 2 = traceback_from(from).
-// One wavefront, one walk: every lane carries the same state (walk_core.h, walk_from_t), lane 0 writes.
-struct WaveWalk {
-    int lane;
-    __device__ bool writer() const { return lane == 0; }
-    // Cells (i-l, j-l), l = 0..63, fetched by lane l.  Returns the number L of leading cells that are plain diagonal steps
-    // (traceback code MV_DIAG: source = the cell up-left in the same contig) with row >= 2 and 1 <= column < n (row 1 can
-    // hold the circular jump, column n the fix-up overrides: both stay on the literal path); their operations are written
-    // by the lanes themselves.
-    __device__ uint32_t diag_run(const JobView& V, uint32_t cur, uint32_t i, uint32_t j, uint32_t nops, OpRec* ops, uint32_t ops_cap) const {
-        const uint32_t l = (uint32_t)lane;
-        const bool inb = l + 2 <= i && l + 1 <= j && j - l < V.n;
-        bool ok = false, match = false;
-        if (inb) {
-            const ContigDesc d = V.cd[cur];
-            const uint32_t ii = i - l, jj = j - l;
-            const uint32_t raw = V.tb[(size_t)(jj - 1) * V.Rtot + d.roff + tb_row_offset(V.tb_keyfmt, d, ii)];
-            const uint32_t code = (V.tb_keyfmt == 1 || V.tb_keyfmt == 2) ? key_code_to_generic(raw, false) : raw;
-            ok = (code & 7u) == MV_DIAG;
-            match = V.xseq[d.seqoff + ii - 1] == V.y[jj - 1];
-        }
-        const unsigned long long bad = ~__ballot(ok);
-        const uint32_t L = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
-        if (l < L && nops + l < ops_cap) { OpRec o; o.kind = match ? OP_MATCH : OP_SUBST; o.pad = 0; o.contig = 0; o.arg = 0; ops[nops + l] = o; }
-        return L;
-    }
-    __device__ void reverse(OpRec* ops, uint32_t nops) const {
-        for (uint32_t a = (uint32_t)lane; a < nops / 2; a += 64) { const OpRec t = ops[a]; ops[a] = ops[nops - 1 - a]; ops[nops - 1 - a] = t; }
-    }
-};
+// (WaveWalk, the wavefront-wide execution of one walk, lives in walk_core.h: fill_regs.hip's persistent teams run it too)
 
-__global__ __launch_bounds__(64) void fixup_walk_kernel(const JobView* __restrict__ jobs, const WalkArgs* __restrict__ args) {
+__global__ __launch_bounds__(64) void fixup_walk_kernel(const JobView* __restrict__ jobs, const WalkArgs* __restrict__ args, uint32_t fixups_done) {
     const JobView& V = jobs[blockIdx.x];
     const WalkArgs A = args[blockIdx.x];
     const int lane = threadIdx.x;
-    if (!A.skip_fixup) for (uint32_t k = lane; k < V.nact; k += 64) fixup_contig(V, V.act[k]);
+    if (!A.skip_fixup && !fixups_done) for (uint32_t k = lane; k < V.nact; k += 64) fixup_contig(V, V.act[k]);
     __syncthreads();
     if (A.mode == 1) {
         // traceback_all candidates: one chain per active contig, walked by walk_all_kernel (one wavefront each)
@@ -293,21 +265,47 @@ __global__ __launch_bounds__(64) void fixup_walk_kernel(const JobView* __restric
     }
 }
 
-// mode 1 (--suboptimal): the walk from every active contig's end cell, one wavefront per (job, contig)
-__global__ __launch_bounds__(64) void walk_all_kernel(const JobView* __restrict__ jobs, const WalkArgs* __restrict__ args, uint32_t stride) {
-    const uint32_t job = blockIdx.x / stride, k = blockIdx.x % stride;
+// the last-column fix-ups alone, 64 contigs per workgroup (one lane each): `chunks` workgroups per job
+__global__ __launch_bounds__(64) void fixup_only_kernel(const JobView* __restrict__ jobs, const WalkArgs* __restrict__ args, uint32_t chunks) {
+    const uint32_t job = blockIdx.x / chunks, k = (blockIdx.x % chunks) * 64u + threadIdx.x;
     const JobView& V = jobs[job];
-    const WalkArgs A = args[job];
-    if (A.mode != 1 || k >= V.nact) return;
-    ChainHdr H;
-    WaveWalk ex; ex.lane = threadIdx.x;
-    walk_from_t(V, V.act[k], H, A.ops + (size_t)k * A.ops_cap, A.ops_cap, ex);
-    if (threadIdx.x == 0) A.hdr[k] = H;
+    if (!args[job].skip_fixup && k < V.nact) fixup_contig(V, V.act[k]);
 }
 
-void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, uint32_t max_nact_mode1, hipStream_t stream) {
-    hipLaunchKernelGGL(fixup_walk_kernel, dim3(n_jobs), dim3(64), 0, stream, d_jobs, d_args);
-    if (max_nact_mode1) hipLaunchKernelGGL(walk_all_kernel, dim3(n_jobs * max_nact_mode1), dim3(64), 0, stream, d_jobs, d_args, max_nact_mode1);
+// mode 1 (--suboptimal): the walk from every active contig's end cell, one wavefront per (job, contig).  Launched with one wavefront per
+// workgroup and one workgroup per walk, or (persistent teams resident: the walks only get the wave slots the fill left free, a few
+// half-empty CUs) with a handful of workgroups of WALK_WAVES wavefronts that stride over the walks.
+constexpr uint32_t WALK_WAVES = 8;         // two per SIMD beside one resident fill wave (96 registers each, no LDS)
+__global__ __launch_bounds__(64 * WALK_WAVES) void walk_all_kernel(const JobView* __restrict__ jobs, const WalkArgs* __restrict__ args, uint32_t stride, uint32_t total) {
+    const uint32_t waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+    for (uint32_t item = blockIdx.x * waves + wave; item < total; item += gridDim.x * waves) {
+        const uint32_t job = item / stride, k = item % stride;
+        const JobView& V = jobs[job];
+        const WalkArgs A = args[job];
+        if (A.mode != 1 || k >= V.nact) continue;
+        ChainHdr H;
+        WaveWalk ex; ex.lane = threadIdx.x & 63;
+        walk_from_t(V, V.act[k], H, A.ops + (size_t)k * A.ops_cap, A.ops_cap, ex);
+        if ((threadIdx.x & 63) == 0) A.hdr[k] = H;
+    }
+}
+
+// max_wgs == 0: as many workgroups as there are jobs / walks.  max_wgs > 0 (persistent teams are resident: stitch_api.cpp
+// run_jobs_streaming): no launch has more than max_wgs workgroups — the fix-ups run 64 contigs per workgroup in a launch of their own
+// (the caller keeps n_jobs x ceil(max_nact / 64) within max_wgs), the walks of --suboptimal stride over their (job, contig) pairs.
+void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, uint32_t max_nact_mode1, hipStream_t stream, uint32_t max_wgs, uint32_t max_nact) {
+    if (max_wgs == 0) {
+        hipLaunchKernelGGL(fixup_walk_kernel, dim3(n_jobs), dim3(64), 0, stream, d_jobs, d_args, 0u);
+        if (max_nact_mode1) hipLaunchKernelGGL(walk_all_kernel, dim3(n_jobs * max_nact_mode1), dim3(64), 0, stream, d_jobs, d_args, max_nact_mode1, n_jobs * max_nact_mode1);
+        return;
+    }
+    const uint32_t chunks = (max_nact + 63u) / 64u;
+    if (chunks > 1) {
+        hipLaunchKernelGGL(fixup_only_kernel, dim3(n_jobs * chunks), dim3(64), 0, stream, d_jobs, d_args, chunks);
+        hipLaunchKernelGGL(fixup_walk_kernel, dim3(n_jobs), dim3(64), 0, stream, d_jobs, d_args, 1u);
+    }
+    else hipLaunchKernelGGL(fixup_walk_kernel, dim3(n_jobs), dim3(64), 0, stream, d_jobs, d_args, 0u);
+    if (max_nact_mode1) { const uint32_t total = n_jobs * max_nact_mode1; const uint32_t wgs = (total + WALK_WAVES - 1) / WALK_WAVES; hipLaunchKernelGGL(walk_all_kernel, dim3(wgs < max_wgs ? wgs : max_wgs), dim3(64 * WALK_WAVES), 0, stream, d_jobs, d_args, max_nact_mode1, total); }
 }
 
 }  // namespace stitch

@@ -253,7 +253,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     const uint2 wm = wave_map[wv];
     // (tell the compiler these are uniform, so that everything read through V is scalar)
     const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm.x);       // classic launch: the job; persistent teams: the team
-    const uint32_t kmine = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm.y);      // this wave's contig: active contig number
+    const uint32_t kmine = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wm.y & 0x3FFFFFFFu));      // this wave's contig: active contig number
+    // (experiment, STITCH_REGS_MAP=2) bit 30: the host has dealt this team's waves to workgroups of one XCD and asks for PLAIN granule stores:
+    // they stay in that XCD's L2, where the team's sc1 polls (L1-bypassing, L2-served) find them without the trip through the fabric
+    const uint32_t gran_aux = ((uint32_t)__builtin_amdgcn_readfirstlane((int)wm.y) & 0x40000000u) ? (uint32_t)AUX_VOLATILE : (uint32_t)(AUX_SC1 | AUX_VOLATILE);
+    if (kmine == 0x3FFFFFFFu) return;               // a padding entry of the wave map
     const bool streaming = qp != nullptr;           // (the queue's words are read through qp where they are needed: two scalar registers across the column loop, not fifteen)
     // ---- persistent teams: one round of this loop per read the team aligns (a classic launch leaves after the first) -----------------
     for (uint32_t seq = 1;; ++seq) {
@@ -385,16 +389,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     const int32_t circular = P.circular;
     int32_t gmax = 0;                                                     // best score of any contig in columns < j (row 0 holds 0)
     // the contigs' column arg-max of column j-1, lane l holding active contigs l, l + 64, ...: {column, score, len, from} granules
-    unsigned long long gv[NQ]; uint32_t actid[NQ];      // ... and their aligner ids
+    unsigned long long gv[NQ];
 #pragma unroll
-    for (int qq = 0; qq < NQ; ++qq) { gv[qq] = 0ull; actid[qq] = 0u; }
+    for (int qq = 0; qq < NQ; ++qq) gv[qq] = 0ull;
 #pragma unroll
     for (int qq = 0; qq < NQ; ++qq) {
         const uint32_t k = (uint32_t)lane + 64u * qq;
-        if (k < nact) actid[qq] = V.act[k];
         if (k < nact) { const JumpBase b = sh.base0[V.act[k]]; gv[qq] = ((unsigned long long)(uint32_t)(b.score & 0xFFFF) << 32) | ((unsigned long long)(b.len & 0xFFFFu) << 16) | (b.from & 0xFFFFu); gmax = b.score > gmax ? b.score : gmax; }
     }
     gmax = (int32_t)wave_max_u32((uint32_t)gmax);
+    // More than one granule register per lane (NQ > 1: up to 256 contigs): the records are only needed from the poll to the end of the jump
+    // selection, so they must not stay in registers across the sweeps (eight registers the sweeps do not have: the kernel went to scratch
+    // memory, which a persistent launch must not use).  Column 1 takes its records (column 0's, from the host) out of LDS.
+    unsigned long long* const g_stash = (unsigned long long*)(s_wave + LDS_TB);
+    if (NQ > 1) {
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) g_stash[lane + 64 * qq] = gv[qq];
+    }
 
     // descriptors of the arrays written with buffer stores (scalar base + lane offset: no address arithmetic in vector registers)
     const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((uint8_t*)V.D + 8ull * roff, 0, 0x7FFFFFFF, RSRC_WORD3);
@@ -458,6 +469,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
 #pragma unroll
                 for (int qq = 0; qq < NQ; ++qq) {
                     const uint32_t k = (uint32_t)lane_p + 64u * qq;
+                    if (NQ > 1) gv[qq] = 0ull;
                     if (k < nact) {
                         const u32x2 g2 = __builtin_amdgcn_raw_buffer_load_b64(rxc, 8u * k, gso, AUX_SC1 | AUX_VOLATILE);
                         // (the wave's OWN granule is not waited for: it knows what it wrote, and the store's round trip through the
@@ -485,6 +497,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
             const int32_t colmax = (int32_t)wave_max_u32(best);
             gmax = colmax > gmax ? colmax : gmax;
         }
+        else if (NQ > 1) {
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq) gv[qq] = g_stash[lane + 64 * qq];
+        }
         RPROF(0)
 #ifdef STITCH_PROFILE
         pf_p1 = pf_t; pf_p0 = pf_c0;
@@ -495,21 +511,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
 
         // ---- best jump out of column j-1 for this contig (multi_contig_aligner.rs:292-331): inter-contig = max by (score, len),
         // LAST aligner on full ties (max_by_key); the records of active contig k sit in lane k % 64, register k / 64
-        auto rec_of = [&](uint32_t k) -> unsigned long long {
-            const uint32_t w = k >> 6;
-            unsigned long long v = gv[0];
+        if (NQ > 1 && j > 1) {      // (this column's records where rec_of finds them; column 1's are there already)
 #pragma unroll
-            for (int qq = 1; qq < NQ; ++qq) v = w == (uint32_t)qq ? gv[qq] : v;
+            for (int qq = 0; qq < NQ; ++qq) g_stash[lane + 64 * qq] = gv[qq];
+        }
+        auto rec_of = [&](uint32_t k) -> unsigned long long {
+            if (NQ > 1) {           // from LDS (every lane reads the one address): picking among NQ registers by a run-time index put the records in scratch memory
+                const unsigned long long v = g_stash[k];
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+                return ((unsigned long long)hi << 32) | lo;
+            }
+            const unsigned long long v = gv[0];
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)(k & 63u)), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)(k & 63u));
             return ((unsigned long long)hi << 32) | lo;
         };
-        auto act_of = [&](uint32_t k) -> uint32_t {
-            const uint32_t w = k >> 6;
-            uint32_t v = actid[0];
-#pragma unroll
-            for (int qq = 1; qq < NQ; ++qq) v = w == (uint32_t)qq ? actid[qq] : v;
-            return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(k & 63u));
-        };
+        auto act_of = [&](uint32_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)V.act[k]); };      // (a scalar load: its result only goes into the jump table)
         JumpInfo ji;
         {
             // the best OTHER contig (not this one, not its opposite strand): 0 = none, else its position in the active list + 1
@@ -755,7 +771,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
             if (lane == 0) {
                 const unsigned long long gran = own_gran;
                 u32x2 g2; g2.x = (uint32_t)gran; g2.y = (uint32_t)(gran >> 32);
-                __builtin_amdgcn_raw_buffer_store_b64(g2, rxc, 0u, ((j & 1u) * C + kmine) * 8u, AUX_SC1 | AUX_VOLATILE);   // one aligned 8-byte write, agent scope
+                // one aligned 8-byte write, agent scope (the aux bits must be an immediate)
+                if (gran_aux == (uint32_t)AUX_VOLATILE) __builtin_amdgcn_raw_buffer_store_b64(g2, rxc, 0u, ((j & 1u) * C + kmine) * 8u, AUX_VOLATILE);
+                else __builtin_amdgcn_raw_buffer_store_b64(g2, rxc, 0u, ((j & 1u) * C + kmine) * 8u, AUX_SC1 | AUX_VOLATILE);
             }
             // the x-suffix running maximum's row (1-based; 0: none): the topmost row holding the largest WORD
             if (xw == 0u) xb_.row = m > 1 ? 1u : 0u;

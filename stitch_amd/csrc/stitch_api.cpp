@@ -53,7 +53,7 @@ struct StreamCtl {                      // == fill_common.h (persistent teams of
     uint32_t* next; uint32_t* cnt; unsigned long long* mbox; uint32_t* h_ready; uint32_t* h_abort; uint32_t* h_done; uint32_t* h_err; uint32_t n_jobs;
 };
 void launch_fill(const JobView* d_jobs, uint32_t n_jobs, int waves, const FillShared& sh, hipStream_t stream);
-void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, uint32_t max_nact_mode1, hipStream_t stream);
+void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, uint32_t max_nact_mode1, hipStream_t stream, uint32_t max_wgs = 0, uint32_t max_nact = 0);
 constexpr size_t PIN_BYTES = (size_t)64 << 20;   // pinned staging buffer for result downloads
 constexpr uint32_t TILE_ROWS = 512;   // 64 lanes x 8 rows (Local-mode kernel; the generic one uses 256): contig row blocks are padded to this
 void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, uint32_t slots_cap, const FillShared& sh, hipStream_t stream);
@@ -624,7 +624,7 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
     *handled = false;
     const size_t N = jobs.size();
     const Knobs& kn = c.knobs;
-    if (kn.no_stream || kn.debug || kn.profile_dump || kn.fill_only || !kn.dump_dir.empty() || kn.no_pipeline || kn.fail_first_attempt || kn.force_regs32 || kn.regs_map) return STITCH_OK;
+    if (kn.no_stream || kn.debug || kn.profile_dump || kn.fill_only || !kn.dump_dir.empty() || kn.no_pipeline || kn.fail_first_attempt || kn.force_regs32 || kn.regs_map == 1) return STITCH_OK;
     if (N < 2 || c.regs_wg_per_cu <= 0) return STITCH_OK;
     const uint32_t W = (uint32_t)jobs[0].act.size();
     for (const Job& jb : jobs) if (jb.act.size() != W || jb.y.size() < 2 || regs_plan(c, jb) == 0) return STITCH_OK;
@@ -645,7 +645,7 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
     if (c.mem_limit) budget = std::min(budget, c.mem_limit);
     // behind the blocks: job table, walk arguments, the jobs' inputs, their exchange granules + error words, wave counters, mailboxes, queue head, wave map, the control block
     const size_t fixed = align_up(sizeof(JobView) * N, 256) + align_up(sizeof(WalkArgs) * N, 256) + in_total + xbytes * N + align_up(4 * N, 256) + align_up(8 * T, 256) + 256 +
-                         align_up(sizeof(uint2) * T * W + 64, 256) + 256 + ((size_t)1 << 20);
+                         align_up(sizeof(uint2) * (T * W + 1024) + 64, 256) + 256 + ((size_t)1 << 20);
     // blocks at multiples of a large power of two, like the classic windows (the jobs' streams want to be congruent)
     size_t a_pick = 0, stride = 0, B = 0;
     for (size_t a = (size_t)1 << 30; a >= 256; a >>= 1) {
@@ -679,7 +679,7 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
     unsigned long long* const d_mbox = (unsigned long long*)carve(8 * T);
     uint32_t* const d_next = (uint32_t*)carve(256);
     const size_t zero_bytes = (size_t)(tail - d_zero);
-    uint2* const d_wave_map = (uint2*)carve(sizeof(uint2) * T * W + 64);
+    uint2* const d_wave_map = (uint2*)carve(sizeof(uint2) * (T * W + 1024) + 64);
     StreamCtl* const d_ctl = (StreamCtl*)carve(256);
     if ((size_t)(tail - c.arena) > c.arena_bytes) return fail(STITCH_EINTERNAL, "arena overflow (persistent teams)");
     // pinned words: [0] ready, [16] abort, [32] err (a cache line each), [64 ..] done[N]
@@ -741,7 +741,20 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
         c.tm.cells += (uint64_t)L.n * [&] { uint64_t s2 = 0; for (uint32_t a : jb.act) s2 += c.al[a].m; return s2; }();
     }
     std::vector<uint2> wave_map; wave_map.reserve(T * W);
-    for (uint32_t t = 0; t < (uint32_t)T; ++t) for (uint32_t k = 0; k < W; ++k) wave_map.push_back(make_uint2(t, k));
+    const size_t per_xcd = (T + 7) / 8;
+    if (kn.regs_map == 2 && per_xcd * W <= (size_t)(c.n_cus / 8) * c.regs_wg_per_cu * c.regs_waves) {
+        // (experiment) a team's waves in workgroups of ONE XCD: workgroup b goes to XCD b mod 8 (observed dispatch order, no guarantee), so
+        // XCD x's workgroups x, x + 8, ... hold the teams x, x + 8, ... one after the other; bit 30 asks for plain granule stores
+        const size_t wg_per_xcd = (per_xcd * W + c.regs_waves - 1) / c.regs_waves;
+        wave_map.assign(8 * wg_per_xcd * c.regs_waves, make_uint2(0u, 0xFFFFFFFFu));
+        for (size_t x = 0; x < 8; ++x) for (size_t sl = 0; sl < per_xcd * W; ++sl) {
+            const size_t t = x + 8 * (sl / W);
+            if (t >= T) continue;
+            const size_t wg = 8 * (sl / c.regs_waves) + x;
+            wave_map[wg * c.regs_waves + sl % c.regs_waves] = make_uint2((uint32_t)t, (uint32_t)(sl % W) | (getenv("STITCH_EXP_PLAIN_GRANULES") ? 0x40000000u : 0u));
+        }
+    }
+    else for (uint32_t t = 0; t < (uint32_t)T; ++t) for (uint32_t k = 0; k < W; ++k) wave_map.push_back(make_uint2(t, k));
     StreamCtl ctl{}; ctl.next = d_next; ctl.cnt = d_cnt; ctl.mbox = d_mbox; ctl.n_jobs = (uint32_t)N;
     ctl.h_ready = c.pin_q + 0; ctl.h_abort = c.pin_q + 16; ctl.h_err = c.pin_q + 32; ctl.h_done = c.pin_q + 64;
     HIP_TRY(hipMemcpyAsync(d_in, c.pin_h2d, in_total, hipMemcpyHostToDevice, sB));
@@ -773,7 +786,8 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
         // the fill left free, and the dispatcher deals a grid's workgroups to the XCDs (and their shader engines) in a fixed rotation: a
         // workgroup whose turn falls on a full engine waits there although another has room.  Measured (gpurun_out/r4b, r4c): walks of up
         // to six workgroups beside 2000 resident fill waves take their 7-9 ms, walks of 14 or more never start until fill waves leave.
-        const size_t range_cap = kn.stream_range > 0 ? (size_t)kn.stream_range : 8;
+        const uint32_t walk_wgs = 8;
+        const size_t range_cap = kn.stream_range > 0 ? (size_t)kn.stream_range : std::max<size_t>(1, walk_wgs / ((W + 63) / 64));      // (fix-ups: 64 contigs per workgroup)
         while (b < N && hq[64 + b] != 0u && b - fin < range_cap) ++b;
         if (b == fin) {
             if (hq[32] != 0u) { broken = true; break; }                            // a wave gave up waiting (partner not resident, lost mailbox)
@@ -786,7 +800,7 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
         uint32_t max_nact_mode1 = 0;
         for (size_t k = fin; k < b; ++k) if (jobs[k].mode == 1) max_nact_mode1 = std::max(max_nact_mode1, lay[k].nact);
         HIP_TRY(hipEventRecord(ev[2], sB));
-        launch_fixup_walk(d_views + fin, d_wargs + fin, nj, max_nact_mode1, sB);
+        launch_fixup_walk(d_views + fin, d_wargs + fin, nj, max_nact_mode1, sB, walk_wgs, W);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[3], sB));
         const double tr0 = kn.trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count() : 0.0;

@@ -4,6 +4,7 @@
 //   pick_primary  == traceback                                                (align/traceback/mod.rs:129-150)
 // Both are serial per (read, contig) like the reference; on the GPU one lane runs each of them.
 #pragma once
+#include <type_traits>
 #include "dp_core.h"
 
 namespace stitch {
@@ -160,51 +161,57 @@ STITCH_HD void fixup_contig(const JobView& V, uint32_t c) {
     // at a time (independent loads) and handed to the row bodies below as `cur`; for i == m `cur` IS the row-m register.
     int32_t Sm_reg = V.S[roff + m - 1];
     auto Sstore = [&](uint32_t i, int32_t v) { if (i >= 1) V.S[roff + i - 1] = v; };
-    auto cell = [&](uint32_t i) -> SCell {
-        if (i == 0) return c0;
+    // (row 0's cell lives in registers; `is0` is a compile-time constant so that no access ever selects between the register copy
+    // and memory through a pointer, which would put the copy on the stack: the kernels that run beside persistent teams must not use
+    // scratch memory at all, DESIGN.md 4 "Persistent teams")
+    auto cell_mem = [&](uint32_t i) -> SCell {
         uint32_t r = roff + i - 1; SCell s; s.len = V.Slen[r];
         if (V.SmoveF[r] != TB_NONE) { s.tb = V.SmoveF[r]; s.idx = V.SidxF[r]; s.from = V.SfromF[r]; }
         else { uint32_t code = tb_byte(V, c, i, n); s.tb = decode_move(V, c, i, n, code); decode_src(V, c, i, n, code, s.idx, s.from); }
         return s;
     };
-    auto cell_set = [&](uint32_t i, uint32_t tb, uint32_t len, uint32_t idx, uint32_t from) {
-        if (i == 0) { c0.tb = tb; c0.len = len; c0.idx = idx; c0.from = from; return; }
+    auto cell_set_mem = [&](uint32_t i, uint32_t tb, uint32_t len, uint32_t idx, uint32_t from) {
         uint32_t r = roff + i - 1;
         V.SmoveF[r] = (uint8_t)tb; V.Slen[r] = len; V.SidxF[r] = idx; V.SfromF[r] = from;
     };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr uint32_t BLK = 32;      // rows whose S / Sn (pass 2: S / I) are loaded at once: the scan is a chain of memory round trips, 2 x m / BLK of them
+#else
     constexpr uint32_t BLK = 8;
+#endif
     // pass 1, one row (:458-517).  `cur` = S[curr][i]
-    auto row1 = [&](uint32_t i, int32_t& cur, int32_t sn) {
+    auto row1 = [&](auto is0, uint32_t i, int32_t& cur, int32_t sn) {
+        constexpr bool ROW0 = decltype(is0)::value;
         // (a) jump over the remaining bases of x (:460-466)
         if (cur + P.jump_same > Sm_reg) {
             Sm_reg = cur + P.jump_same; Sstore(m, Sm_reg);
-            SCell ps = cell(i);
-            cell_set(m, TB_XJUMP, ps.len, ps.idx, i);
+            SCell ps; if constexpr (ROW0) ps = c0; else ps = cell_mem(i);
+            cell_set_mem(m, TB_XJUMP, ps.len, ps.idx, i);
         }
         // (b) y suffix clip (:469-491); the equal branch compares a cell's length with itself
         if (sn > cur) {
             cur = sn; Sstore(i, sn);
-            uint32_t ly = i == 0 ? ly0 : V.Ly[roff + i - 1];
-            uint32_t len = i == 0 ? (n - ly == 0 ? 0u : row0_at(P, n - ly, n).Slen) : V.SnLen[roff + i - 1];
-            (void)ly;
-            cell_set(i, TB_YCLIP_SUFFIX, len, c, i);     // idx of this cell is never consumed
+            uint32_t len;
+            if constexpr (ROW0) len = n - ly0 == 0 ? 0u : row0_at(P, n - ly0, n).Slen; else len = V.SnLen[roff + i - 1];
+            // idx of this cell is never consumed
+            if constexpr (ROW0) { c0.tb = TB_YCLIP_SUFFIX; c0.len = len; c0.idx = c; c0.from = i; } else cell_set_mem(i, TB_YCLIP_SUFFIX, len, c, i);
         }
         // (c) x suffix clip (:494-516)
         {
             int32_t v = cur + P.xclip_suffix;
             bool do_x = false;
             if (v > Sm_reg) do_x = true;
-            else if (v == Sm_reg) do_x = cell(i).len > cell(m).len;
+            else if (v == Sm_reg) { uint32_t li; if constexpr (ROW0) li = c0.len; else li = cell_mem(i).len; do_x = li > cell_mem(m).len; }
             if (do_x) {
                 Sm_reg = v; Sstore(m, v);
                 *LxN = m - i;
-                SCell ps = cell(i);
-                cell_set(m, TB_XCLIP_SUFFIX, ps.len, ps.idx, i);
+                SCell ps; if constexpr (ROW0) ps = c0; else ps = cell_mem(i);
+                cell_set_mem(m, TB_XCLIP_SUFFIX, ps.len, ps.idx, i);
             }
         }
     };
-    row1(0, S0, sn0);
+    row1(std::true_type(), 0, S0, sn0);
     for (uint32_t b0 = 1; b0 <= m; b0 += BLK) {
         int32_t Sb[BLK], Snb[BLK];
 #pragma unroll
@@ -212,7 +219,7 @@ STITCH_HD void fixup_contig(const JobView& V, uint32_t c) {
 #pragma unroll
         for (uint32_t k = 0; k < BLK; ++k) {
             const uint32_t i = b0 + k;
-            if (i < m) row1(i, Sb[k], Snb[k]); else if (i == m) row1(i, Sm_reg, Snb[k]);
+            if (i < m) row1(std::false_type(), i, Sb[k], Snb[k]); else if (i == m) row1(std::false_type(), i, Sm_reg, Snb[k]);
         }
     }
     // pass 2, one row (:521-554).  `above` = S[curr][i-1] after its own update, `cur` = S[curr][i], `ival` = I[curr][i]
@@ -221,17 +228,17 @@ STITCH_HD void fixup_contig(const JobView& V, uint32_t c) {
         int32_t i_score = above + P.gap_open + P.gap_extend;
         if (i_score > ival) {
             V.Ival[r] = i_score;
-            SCell sv = cell(i - 1);
+            SCell sv; if (i == 1) sv = c0; else sv = cell_mem(i - 1);
             V.ImoveF[r] = (uint8_t)sv.tb; V.Ilen[r] = sv.len + 1;
         }
         if (i_score > cur) {
             cur = i_score; Sstore(i, i_score);
             uint32_t prev_len = V.Ilen[r];
-            cell_set(i, TB_INS, prev_len, c, i - 1);
+            cell_set_mem(i, TB_INS, prev_len, c, i - 1);
             if (cur + P.xclip_suffix > Sm_reg) {
                 Sm_reg = cur + P.xclip_suffix; Sstore(m, Sm_reg);
                 *LxN = m - i;
-                cell_set(m, TB_XCLIP_SUFFIX, prev_len, c, i);
+                cell_set_mem(m, TB_XCLIP_SUFFIX, prev_len, c, i);
             }
         }
     };
@@ -247,7 +254,7 @@ STITCH_HD void fixup_contig(const JobView& V, uint32_t c) {
         }
     }
     V.Sm[c] = Sm_reg;
-    V.Lm[c] = cell(m).len;
+    V.Lm[c] = cell_mem(m).len;
 }
 
 // traceback (align/traceback/mod.rs:129-150): best end contig among the active aligners, in aligner order
@@ -380,5 +387,37 @@ STITCH_HD void walk_from_t(const JobView& V, uint32_t contig_index, ChainHdr& H,
     H.start_contig_idx = cur; H.end_contig_idx = contig_index; H.length = alignment_length; H.n_ops = nops;
 }
 STITCH_HD void walk_from(const JobView& V, uint32_t contig_index, ChainHdr& H, OpRec* ops, uint32_t ops_cap) { walk_from_t(V, contig_index, H, ops, ops_cap, SoloWalk()); }
+
+#if defined(__HIPCC__)
+// One wavefront, one walk: every lane carries the same state (walk_core.h, walk_from_t), lane 0 writes.
+struct WaveWalk {
+    int lane;
+    __device__ bool writer() const { return lane == 0; }
+    // Cells (i-l, j-l), l = 0..63, fetched by lane l.  Returns the number L of leading cells that are plain diagonal steps
+    // (traceback code MV_DIAG: source = the cell up-left in the same contig) with row >= 2 and 1 <= column < n (row 1 can
+    // hold the circular jump, column n the fix-up overrides: both stay on the literal path); their operations are written
+    // by the lanes themselves.
+    __device__ uint32_t diag_run(const JobView& V, uint32_t cur, uint32_t i, uint32_t j, uint32_t nops, OpRec* ops, uint32_t ops_cap) const {
+        const uint32_t l = (uint32_t)lane;
+        const bool inb = l + 2 <= i && l + 1 <= j && j - l < V.n;
+        bool ok = false, match = false;
+        if (inb) {
+            const ContigDesc d = V.cd[cur];
+            const uint32_t ii = i - l, jj = j - l;
+            const uint32_t raw = V.tb[(size_t)(jj - 1) * V.Rtot + d.roff + tb_row_offset(V.tb_keyfmt, d, ii)];
+            const uint32_t code = (V.tb_keyfmt == 1 || V.tb_keyfmt == 2) ? key_code_to_generic(raw, false) : raw;
+            ok = (code & 7u) == MV_DIAG;
+            match = V.xseq[d.seqoff + ii - 1] == V.y[jj - 1];
+        }
+        const unsigned long long bad = ~__ballot(ok);
+        const uint32_t L = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+        if (l < L && nops + l < ops_cap) { OpRec o; o.kind = match ? OP_MATCH : OP_SUBST; o.pad = 0; o.contig = 0; o.arg = 0; ops[nops + l] = o; }
+        return L;
+    }
+    __device__ void reverse(OpRec* ops, uint32_t nops) const {
+        for (uint32_t a = (uint32_t)lane; a < nops / 2; a += 64) { const OpRec t = ops[a]; ops[a] = ops[nops - 1 - a]; ops[nops - 1 - a] = t; }
+    }
+};
+#endif
 
 }  // namespace stitch

@@ -81,6 +81,8 @@ def main():
     al.align_packed_raw(*pack(reads[:min(batch, len(reads))]))                   # warm-up: first launch, arena allocation at its final size
     tot = dict(fill_ms=0.0, walk_ms=0.0, prealign_ms=0.0, prealign_host_ms=0.0, h2d_ms=0.0, d2h_ms=0.0, cells=0, launches=0)
     n_chains = n_bad = mapped = 0
+    import hashlib
+    digest = hashlib.sha256()                     # of every result record and operation: two runs of one configuration (persistent teams or launch by launch) must agree
     t0 = time.perf_counter()
     t_check = 0.0
     for s in range(0, len(reads), batch):
@@ -89,6 +91,7 @@ def main():
         for k in tot:
             tot[k] += tm.get(k, 0)
         tc = time.perf_counter()
+        digest.update(np.ascontiguousarray(rr).tobytes()); digest.update(np.ascontiguousarray(ch).tobytes()); digest.update(np.ascontiguousarray(op).tobytes())
         opw = op.view(np.uint64) if len(op) else np.zeros(0, dtype=np.uint64)
         for c in ch:
             n_chains += 1
@@ -99,7 +102,7 @@ def main():
     dt = time.perf_counter() - t0 - t_check
     out = {"config": args.config, "mode": args.mode, "fill_kind": al.timing().get("fill_kind"), "reads": len(reads), "batch": batch, "seconds": dt, "reads_per_sec": len(reads) / dt,
            "gcells_per_sec": tot["cells"] / dt / 1e9, "chains": n_chains, "chains_whose_ops_do_not_rescore": None if args.config == "cfg5" else n_bad,
-           "reads_with_chains": mapped, **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in tot.items()}}
+           "reads_with_chains": mapped, "results_sha256": digest.hexdigest()[:16], "stream_runs": al.timing().get("stream_runs"), "fallbacks": al.timing().get("fallbacks"), **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in tot.items()}}
 
     if args.config == "cfg1":                                                  # small enough for the oracle: full comparison
         from oracle import oracle as orc
