@@ -255,7 +255,20 @@ __global__ __launch_bounds__(64) void fixup_walk_kernel(const JobView* __restric
     if (!A.skip_fixup && !fixups_done) for (uint32_t k = lane; k < V.nact; k += 64) fixup_contig(V, V.act[k]);
     __syncthreads();
     if (A.mode == 1) {
-        // traceback_all candidates: one chain per active contig, walked by walk_all_kernel (one wavefront each)
+        // traceback_all candidates: one chain per active contig, walked by walk_all_kernel (one wavefront each).  This kernel walks the
+        // REFERENCE chain — the one from the best end contig — and records where it enters every column; the others stop where they meet
+        // it (walk_core.h, VisitRec)
+        if (V.visit != nullptr) {
+            const uint32_t r = pick_primary(V);
+            uint32_t kr = 0;
+            for (uint32_t k = 0; k < V.nact; ++k) if (V.act[k] == r) kr = k;
+            for (uint32_t e = (uint32_t)lane; e < V.n + 2; e += 64) { VisitRec z; z.contig = e == 0 ? (uint16_t)kr : (uint16_t)0xFFFFu; z.row = 0; z.layer = 0xFFFFFFFFu; z.nops = 0; z.nonspecial = 0; V.visit[e] = z; }
+            __syncthreads();
+            ChainHdr H;
+            WaveWalk ex; ex.lane = lane; ex.role = 1; ex.ref_slot = kr;
+            walk_from_t(V, r, H, A.ops + (size_t)kr * A.ops_cap, A.ops_cap, ex);
+            if (lane == 0) A.hdr[kr] = H;
+        }
     } else {
         const uint32_t c = A.mode == 0 ? pick_primary(V) : A.from;
         ChainHdr H;
@@ -285,6 +298,11 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void walk_all_kernel(const JobView
         if (A.mode != 1 || k >= V.nact) continue;
         ChainHdr H;
         WaveWalk ex; ex.lane = threadIdx.x & 63;
+        if (V.visit != nullptr) {
+            const VisitRec sum = V.visit[0];
+            if (k == sum.contig) continue;                 // the reference chain: walked by fixup_walk_kernel
+            if (sum.row == 1) { ex.role = 2; ex.ref_hdr = A.hdr + sum.contig; }
+        }
         walk_from_t(V, V.act[k], H, A.ops + (size_t)k * A.ops_cap, A.ops_cap, ex);
         if ((threadIdx.x & 63) == 0) A.hdr[k] = H;
     }
@@ -294,12 +312,15 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void walk_all_kernel(const JobView
 // run_jobs_streaming): no launch has more than max_wgs workgroups — the fix-ups run 64 contigs per workgroup in a launch of their own
 // (the caller keeps n_jobs x ceil(max_nact / 64) within max_wgs), the walks of --suboptimal stride over their (job, contig) pairs.
 void launch_fixup_walk(const JobView* d_jobs, const WalkArgs* d_args, uint32_t n_jobs, uint32_t max_nact_mode1, hipStream_t stream, uint32_t max_wgs, uint32_t max_nact) {
+    const uint32_t chunks = (max_nact + 63u) / 64u;
     if (max_wgs == 0) {
-        hipLaunchKernelGGL(fixup_walk_kernel, dim3(n_jobs), dim3(64), 0, stream, d_jobs, d_args, 0u);
+        // (more than 64 contigs: the fix-ups, one lane per contig and serial down its rows, in workgroups of 64 contigs side by side rather
+        // than in rounds of 64 within the read's one workgroup: cfg5's 200 contigs took four rounds, 75 ms per launch)
+        if (chunks > 1) hipLaunchKernelGGL(fixup_only_kernel, dim3(n_jobs * chunks), dim3(64), 0, stream, d_jobs, d_args, chunks);
+        hipLaunchKernelGGL(fixup_walk_kernel, dim3(n_jobs), dim3(64), 0, stream, d_jobs, d_args, chunks > 1 ? 1u : 0u);
         if (max_nact_mode1) hipLaunchKernelGGL(walk_all_kernel, dim3(n_jobs * max_nact_mode1), dim3(64), 0, stream, d_jobs, d_args, max_nact_mode1, n_jobs * max_nact_mode1);
         return;
     }
-    const uint32_t chunks = (max_nact + 63u) / 64u;
     if (chunks > 1) {
         hipLaunchKernelGGL(fixup_only_kernel, dim3(n_jobs * chunks), dim3(64), 0, stream, d_jobs, d_args, chunks);
         hipLaunchKernelGGL(fixup_walk_kernel, dim3(n_jobs), dim3(64), 0, stream, d_jobs, d_args, 1u);

@@ -274,6 +274,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
             if (lane0 == 0) {
                 if (__hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) idx = atomicAdd(q.next, 1u);
                 if (idx >= q.n_jobs) idx = 0xFFFFFFFFu;
+                // The job's arena block is the one job - blocks used: wait until the host has walked that read and taken its chains.  ONE lane
+                // of the team looks at the host's word, and not often: it lives in pinned host memory, every look is a trip over PCIe (a whole
+                // team looking — 200 waves every 3 us at cfg5, where a run has few spare blocks and teams wait as a rule — slowed every fill
+                // wave and every copy of the process five-fold: gpurun_out/r4j).  Bounded: 40 s; the host ends a run that makes no progress
+                // earlier and says so through h_abort.  The team's other waves wait for the mailbox, i.e. in device memory.
+                if (idx != 0xFFFFFFFFu) {
+                    const uint32_t t0 = (uint32_t)wall_clock64();
+                    for (uint32_t spins = 1;; ++spins) {
+                        if (__hip_atomic_load(q.h_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > idx) break;
+                        if ((spins & 7u) == 0 && (__hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || (uint32_t)wall_clock64() - t0 > 4000000000u)) { idx = 0xFFFFFFFFu; break; }
+                        for (int k = 0; k < 6; ++k) __builtin_amdgcn_s_sleep(127);      // ~20 us between two looks
+                    }
+                }
                 __hip_atomic_store(mb, ((unsigned long long)seq << 32) | idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
@@ -283,26 +296,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
             for (uint32_t spins = 1;; ++spins) {
                 const unsigned long long v = __hip_atomic_load(mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((uint32_t)(v >> 32) == seq) { idx = (uint32_t)v; break; }
-                if ((spins & 255u) == 0 && (uint32_t)wall_clock64() - t0 > 400000000u) {      // 4 s: the team's first wave is gone
+                if ((spins & 255u) == 0 && (uint32_t)wall_clock64() - t0 > 4200000000u) {      // (the first wave's own wait for a block is bounded by 40 s: beyond that it is gone)
                     if (lane0 == 0) __hip_atomic_store(q.h_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     return;
                 }
-                __builtin_amdgcn_s_sleep(16);
+                if (spins < 64u) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127);
             }
             idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
         }
         if (idx == 0xFFFFFFFFu) return;                      // the queue is empty (or the host has called the run off)
         job = idx;
-        // the job's arena block is the one job - blocks used: wait until the host has walked that read and taken its chains (bounded:
-        // 40 s; the host ends a run that makes no progress earlier and says so through h_abort)
-        {
-            const uint32_t t0 = (uint32_t)wall_clock64();
-            for (uint32_t spins = 1;; ++spins) {
-                if (__hip_atomic_load(q.h_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > job) break;
-                if ((spins & 63u) == 0 && (__hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || (uint32_t)wall_clock64() - t0 > 4000000000u)) return;
-                __builtin_amdgcn_s_sleep(127);
-            }
-        }
     }
     const JobView& V = jobs[job];
 #ifdef STITCH_EXP_PRIO

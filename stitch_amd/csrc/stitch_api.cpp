@@ -96,7 +96,7 @@ struct Knobs {
     size_t array_align = 0, job_align = 0;
     std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
-    int regs_waves = 0, regs_map = 0; bool trace = false, no_stream = false; int stream_blocks = 0, stream_teams = 0, stream_range = 0;      // (experiments) waves per workgroup of fill_regs.hip, order of its wave map; launch timeline on stderr
+    int regs_waves = 0, regs_map = 0; bool trace = false, no_stream = false, no_join = false; int stream_blocks = 0, stream_teams = 0, stream_range = 0;      // (experiments) waves per workgroup of fill_regs.hip, order of its wave map; launch timeline on stderr
     static Knobs from_env() {
         Knobs k;
         auto num = [](const char* name) -> unsigned long long { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : 0ull; };
@@ -115,6 +115,7 @@ struct Knobs {
         k.array_align = (size_t)num("STITCH_ARRAY_ALIGN"); k.job_align = (size_t)num("STITCH_JOB_ALIGN");
         k.max_waves = (int)num("STITCH_MAX_WAVES"); k.wg_per_read = (int)num("STITCH_WG_PER_READ"); k.tiles_per_wave = (int)num("STITCH_TILES_PER_WAVE");
         k.regs_waves = (int)num("STITCH_REGS_WAVES"); k.regs_map = (int)num("STITCH_REGS_MAP"); k.trace = getenv("STITCH_TRACE") != nullptr;
+        k.no_join = getenv("STITCH_NO_JOIN") != nullptr;          // traceback_all: every chain walked to its start (A/B runs, tests), none joined to the reference chain
         k.no_stream = getenv("STITCH_NO_STREAM") != nullptr;      // launch by launch even where persistent teams apply (A/B runs, tests)
         k.stream_blocks = (int)num("STITCH_STREAM_BLOCKS");       // (tests) cap on the arena blocks of a persistent-team run
         k.stream_range = (int)num("STITCH_STREAM_RANGE");         // (experiments) most jobs walked by one fix-up + walk launch
@@ -386,7 +387,7 @@ namespace {
 struct JobLayout {
     uint32_t n, nact, Rj, slots, ops_cap;
     size_t off_S, off_Slen, off_D, off_Dlen, off_Sn, off_SnLen, off_Ly, off_Ival, off_Ilen, off_SidxF, off_SfromF, off_SmoveF, off_ImoveF,
-        off_st16, off_xchg, off_tb, off_Lx, off_jti, off_jtf, off_Sm, off_Lm, off_y, off_act, off_opp, off_cd, off_hdr, off_ops, bytes,
+        off_st16, off_xchg, off_tb, off_Lx, off_jti, off_jtf, off_Sm, off_Lm, off_visit, off_y, off_act, off_opp, off_cd, off_hdr, off_ops, bytes,
         stride;              // distance to the next job's block in a launch (bytes rounded up to the launch's block alignment)
 };
 
@@ -415,6 +416,7 @@ JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
     L.off_tb = take_big((size_t)L.n * R);
     L.off_Lx = take(4ull * c.C * (L.n + 1)); L.off_jti = take(4ull * c.C * (L.n + 1)); L.off_jtf = take(4ull * c.C * (L.n + 1));
     L.off_Sm = take(4ull * c.C); L.off_Lm = take(4ull * c.C);
+    L.off_visit = take(jb.mode == 1 ? sizeof(VisitRec) * ((size_t)L.n + 2) : 0);      // traceback_all: the reference walk's column records (walk_core.h)
     L.off_y = take(L.n); L.off_act = take(4ull * L.nact); L.off_opp = take(4ull * c.C); L.off_cd = take(sizeof(ContigDesc) * (size_t)c.C);
     L.off_hdr = take(sizeof(ChainHdr) * (size_t)L.slots); L.off_ops = take(sizeof(OpRec) * (size_t)L.slots * L.ops_cap);
     L.bytes = o;
@@ -538,6 +540,8 @@ int download_chains(stitch_ctx& c, hipStream_t sB, std::vector<Job>& jobs, const
             pend.clear();
             return STITCH_OK;
         };
+        struct Join { uint32_t q, s, ref, n; };
+        std::vector<Join> joins;
         std::vector<std::vector<ChainHdr>> hdrs(nj);
         for (uint32_t q = 0; q < nj; ++q) {
             const JobLayout& L = lay[k0 + q];
@@ -576,6 +580,7 @@ int download_chains(stitch_ctx& c, hipStream_t sB, std::vector<Job>& jobs, const
                 a.score = H.score; a.xstart = H.xstart; a.xend = H.xend; a.ystart = H.ystart; a.yend = H.yend; a.xlen = H.xlen; a.ylen = H.ylen;
                 a.start_contig_idx = H.start_contig_idx; a.end_contig_idx = H.end_contig_idx; a.length = H.length;
                 a.ops.resize(H.n_ops);
+                if (H.join_ops) { if (big || H.join_slot >= L.slots || H.join_slot == s) return fail(STITCH_EINTERNAL, "bad chain join"); joins.push_back({q, s, H.join_slot, H.join_ops}); }
                 static_assert(sizeof(OpRec) == sizeof(stitch_op), "op layout");
                 if (H.n_ops) {
                     if (big) { HIP_TRY(hipMemcpy(a.ops.data(), ops_src, sizeof(OpRec) * (size_t)H.n_ops, hipMemcpyDeviceToHost)); }
@@ -585,6 +590,17 @@ int download_chains(stitch_ctx& c, hipStream_t sB, std::vector<Job>& jobs, const
             }
         }
         if (int e = flush()) return e;
+        // chains that met the reference chain of their read: its first join_ops operations, then their own (walk_core.h, VisitRec)
+        for (const Join& jn : joins) {
+            Job& jb = jobs[k0 + jn.q];
+            const HAln& ref = jb.chains[jn.ref];
+            if (jn.ref >= jb.chains.size() || jb.status[jn.ref] != 0 || jn.n > ref.ops.size()) return fail(STITCH_EINTERNAL, "a chain joins a reference chain that does not hold that many operations");
+            HAln& a = jb.chains[jn.s];
+            std::vector<stitch_op> all; all.reserve((size_t)jn.n + a.ops.size());
+            all.insert(all.end(), ref.ops.begin(), ref.ops.begin() + jn.n);
+            all.insert(all.end(), a.ops.begin(), a.ops.end());
+            a.ops.swap(all);
+        }
         c.tm.d2h_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d2h0).count();
         return STITCH_OK;
 }
@@ -737,6 +753,7 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
         V.SidxF = (uint32_t*)(Bk + L.off_SidxF); V.SfromF = (uint32_t*)(Bk + L.off_SfromF); V.ImoveF = Bk + L.off_ImoveF;
         V.Smove0 = c.d_Smove0; V.Imove0 = c.d_Imove0; V.Slen0 = c.d_Slen0;
         V.Sm = (int32_t*)(Bk + L.off_Sm); V.Lm = (uint32_t*)(Bk + L.off_Lm);
+        V.visit = (jb.mode == 1 && !c.knobs.no_join) ? (VisitRec*)(Bk + L.off_visit) : nullptr;
         WalkArgs& A = wargs[k]; A.hdr = (ChainHdr*)(Bk + L.off_hdr); A.ops = (OpRec*)(Bk + L.off_ops); A.ops_cap = L.ops_cap; A.mode = jb.mode; A.from = jb.from; A.skip_fixup = 0;
         c.tm.cells += (uint64_t)L.n * [&] { uint64_t s2 = 0; for (uint32_t a : jb.act) s2 += c.al[a].m; return s2; }();
     }
@@ -1112,6 +1129,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             V.SidxF = (uint32_t*)(B + L.off_SidxF); V.SfromF = (uint32_t*)(B + L.off_SfromF); V.ImoveF = B + L.off_ImoveF;
             V.Smove0 = c.d_Smove0; V.Imove0 = c.d_Imove0; V.Slen0 = c.d_Slen0;
             V.Sm = (int32_t*)(B + L.off_Sm); V.Lm = (uint32_t*)(B + L.off_Lm);
+            V.visit = (jb.mode == 1 && !c.knobs.no_join) ? (VisitRec*)(B + L.off_visit) : nullptr;
             WalkArgs& A = wargs[q]; A.hdr = (ChainHdr*)(B + L.off_hdr); A.ops = (OpRec*)(B + L.off_ops); A.ops_cap = L.ops_cap; A.mode = jb.mode; A.from = jb.from; A.skip_fixup = 0;
             c.tm.cells += (uint64_t)L.n * [&] { uint64_t s = 0; for (uint32_t a : jb.act) s += c.al[a].m; return s; }();
         }
@@ -1249,7 +1267,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         uint32_t max_nact_mode1 = 0;
         for (uint32_t q = 0; q < nj; ++q) if (jobs[k0 + q].mode == 1) max_nact_mode1 = std::max(max_nact_mode1, lay[k0 + q].nact);
         HIP_TRY(hipEventRecord(ev[2], sB));
-        launch_fixup_walk(d_views, d_wargs, nj, max_nact_mode1, sB);
+        { uint32_t max_nact = 0; for (uint32_t q = 0; q < nj; ++q) max_nact = std::max(max_nact, lay[k0 + q].nact); launch_fixup_walk(d_views, d_wargs, nj, max_nact_mode1, sB, 0, max_nact); }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[3], sB));
         HIP_TRY(hipStreamSynchronize(sB));

@@ -23,6 +23,23 @@ struct ContigDesc {            // one per (contig, strand) aligner
 struct ChainHdr {              // == Alignment (align/alignment.rs:16-51)
     int32_t score; uint32_t xstart, xend, ystart, yend, xlen, ylen;
     uint32_t start_contig_idx, end_contig_idx, length, n_ops, status;   // status: 0 ok, 1 None, 2 overflow, 3 bad move / runaway, 4 reference-undefined XJUMP
+    uint32_t join_ops, join_slot;  // traceback_all only: the chain's operations are the first join_ops operations of chain `join_slot` of the same read
+                                   // followed by the n_ops written for this chain (join_ops == 0: the n_ops are the whole chain)
+};
+
+// traceback_all (--suboptimal) walks from the end of EVERY active contig (align/traceback/mod.rs:152-217).  Nearly all of those walks
+// run into the path of the read's best chain after a few steps (a contig the read does not align to ends its chain with a jump out of
+// the best path's last columns) and then repeat that path's ten or twenty thousand steps.  A walk is a function of its state
+// (contig, row, column, layer move) — plus "the first operation was a y clip", which the x-suffix branch consults and which is required
+// to be false on both sides here — so: the walk of the best contig's chain (the REFERENCE walk) records its state where it first enters
+// each column, and any other walk that enters a column in the recorded state stops there; its chain is the reference chain's
+// operations up to that point (in final order: a prefix) followed by its own.  The host puts the two together (stitch_api.cpp
+// download_chains), so what is downloaded and walked shrinks from contigs x columns to columns + contigs x a few.
+struct VisitRec {              // one per column (entry j + 1; entry 0 is the reference walk's summary)
+    uint16_t contig, row;      // state on entering the column ...   (entry 0: contig = slot of the reference chain, row = 1 if the records are usable)
+    uint32_t layer;            // ... move of the layer the walk is in, | 0x100 if the first operation was a y clip
+    uint32_t nops;             // operations the reference walk had written by then                (entry 0: all of them)
+    uint32_t nonspecial;       // ... of which neither clip nor jump                                 (entry 0: all of them)
 };
 
 constexpr uint32_t ERR_CLOCK_OFF = 3072;   // behind JobView::err: {shader cycles, 100 MHz ticks} of the read's column loop (fill_regs.hip)
@@ -58,6 +75,7 @@ struct JobView {
     const uint8_t* Smove0; const uint8_t* Imove0; const uint32_t* Slen0;   // indexed by ContigDesc::troff
     // per-contig results of the fix-ups
     int32_t* Sm; uint32_t* Lm;                        // [C] S[n%2][m] and cell(m,n).S.len
+    VisitRec* visit;                                  // [n + 2] traceback_all: the reference walk's column records (nullptr: walks do not join)
 };
 
 struct WalkArgs { ChainHdr* hdr; OpRec* ops; uint32_t ops_cap; int32_t mode; uint32_t from; uint32_t skip_fixup; };   // per job
@@ -278,7 +296,13 @@ STITCH_HD bool is_active(const JobView& V, uint32_t c) {
 // fetch 64 cells of the diagonal at once, so the walk pays one memory latency per run instead of one per cell.
 struct SoloWalk {
     STITCH_HD bool writer() const { return true; }
-    STITCH_HD uint32_t diag_run(const JobView&, uint32_t, uint32_t, uint32_t, uint32_t, OpRec*, uint32_t) const { return 0; }
+    STITCH_HD uint32_t diag_run(const JobView&, uint32_t, uint32_t, uint32_t, uint32_t, OpRec*, uint32_t, uint32_t, bool) const { return 0; }
+    STITCH_HD bool enter_column(const JobView&, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, bool) const { return false; }
+    STITCH_HD bool joined() const { return false; }
+    STITCH_HD uint32_t join_nops() const { return 0; }
+    STITCH_HD uint32_t join_nonspecial() const { return 0; }
+    STITCH_HD void finish_reference(const JobView&, uint32_t, uint32_t, bool) const {}
+    STITCH_HD ChainHdr reference_header() const { return ChainHdr{}; }
     STITCH_HD void reverse(OpRec* ops, uint32_t nops) const { for (uint32_t a = 0, b = nops; a + 1 < b; ++a, --b) { OpRec t = ops[a]; ops[a] = ops[b - 1]; ops[b - 1] = t; } }
 };
 
@@ -286,7 +310,7 @@ struct SoloWalk {
 template <typename Exec>
 STITCH_HD void walk_from_t(const JobView& V, uint32_t contig_index, ChainHdr& H, OpRec* ops, uint32_t ops_cap, const Exec& ex) {
     const uint32_t n = V.n;
-    H.status = 0; H.n_ops = 0; H.end_contig_idx = contig_index;
+    H.status = 0; H.n_ops = 0; H.end_contig_idx = contig_index; H.join_ops = 0; H.join_slot = 0;
     if (contig_index >= V.C || !is_active(V, contig_index)) { H.status = 1; return; }
     uint32_t j = n, nops = 0;
     uint32_t xstart = 0, ystart = 0, yend = n;
@@ -300,25 +324,31 @@ STITCH_HD void walk_from_t(const JobView& V, uint32_t contig_index, ChainHdr& H,
     uint64_t max_steps = 2ull * ((uint64_t)n + 2) * ((uint64_t)V.Rtot + 2) + 64;   // free gaps + free jumps can emit ~n*m ops
     if (max_steps > 50000000ull) max_steps = 50000000ull;                           // a runaway walk must end in seconds, not hours
     uint64_t steps = 0;
+    uint32_t nonspecial = 0;                             // operations written so far that are neither clip nor jump
+    uint32_t j_entered = n;                              // the column whose entry the execution policy has seen (the start is not an entry)
     auto push = [&](uint8_t kind, uint32_t contig, uint32_t arg) {
         if (nops < ops_cap) { if (ex.writer()) { OpRec o; o.kind = kind; o.pad = 0; o.contig = (uint16_t)contig; o.arg = arg; ops[nops] = o; } }
         else H.status = 2;
         if (nops == 0) first_kind = kind;
+        if (!(kind == OP_XCLIP || kind == OP_YCLIP || kind == OP_XJUMP)) ++nonspecial;
         ++nops;
     };
     for (;;) {
         if (++steps > max_steps || i > V.cd[cur].m || j > n) { H.status = 3; break; }     // (a walk that leaves the matrix ends with an error, not a fault)
+        // a new column: the reference walk of traceback_all records the state, the others stop where they meet it (VisitRec above)
+        if (j != j_entered) { j_entered = j; if (ex.enter_column(V, cur, i, j, last_layer, nops, nonspecial, first_kind == OP_YCLIP)) break; }
         // (cur is checked against the active set where it changes: at the start and after every jump)
         uint32_t next_layer;
         if (last_layer == TB_START) break;
         if (last_layer == TB_MATCH || last_layer == TB_SUBST) {
             // a run of L cells (i,j), (i-1,j-1), ... that are all plain diagonal steps inside the matrix (row >= 2, column < n):
             // exactly what L turns of the branch below would do, without a jump in between
-            const uint32_t L = ex.diag_run(V, cur, i, j, nops, ops, ops_cap);
+            const uint32_t L = ex.diag_run(V, cur, i, j, nops, ops, ops_cap, nonspecial, first_kind == OP_YCLIP);
             if (L) {
                 if (nops == 0) first_kind = last_layer == TB_MATCH ? OP_MATCH : OP_SUBST;
                 if (nops + L > ops_cap) H.status = 2;
-                nops += L; steps += L; i -= L; j -= L;
+                nops += L; nonspecial += L; steps += L; i -= L; j -= L;
+                if (ex.joined()) { j_entered = j; break; }      // (one of the run's cells was the reference walk's: the run was cut there)
                 last_layer = s_move(V, cur, i, j);
                 continue;
             }
@@ -378,10 +408,21 @@ STITCH_HD void walk_from_t(const JobView& V, uint32_t contig_index, ChainHdr& H,
         } else { H.status = 3; break; }
         last_layer = next_layer;
     }
+    H.join_ops = 0; H.join_slot = 0;
     if (H.status == 2) { H.n_ops = nops; return; }
+    if (H.status == 3) return;
     ex.reverse(ops, nops);
-    bool all_special = true;
-    for (uint32_t k = 0; k < nops; ++k) { uint8_t kd = ops[k].kind; if (!(kd == OP_XCLIP || kd == OP_YCLIP || kd == OP_XJUMP)) { all_special = false; break; } }
+    bool all_special = nonspecial == 0;
+    if (ex.joined()) {
+        // the rest of this walk is the reference walk's from the column where they met: its operations from there on (in final order the
+        // first join_ops of that chain), its start coordinates (set by prefix clips at the very end of a walk), its start contig
+        const VisitRec sum = V.visit[0];
+        const ChainHdr R = ex.reference_header();
+        all_special = all_special && sum.nonspecial == ex.join_nonspecial();
+        xstart = R.xstart; ystart = R.ystart; cur = R.start_contig_idx;
+        H.join_ops = sum.nops - ex.join_nops(); H.join_slot = sum.contig;
+    }
+    ex.finish_reference(V, nops, nonspecial, H.status == 0 && !all_special);
     if (all_special) { xstart = 0; xend = 0; ystart = 0; yend = 0; }
     H.score = score; H.xstart = xstart; H.xend = xend; H.ystart = ystart; H.yend = yend; H.xlen = xlen; H.ylen = n;
     H.start_contig_idx = cur; H.end_contig_idx = contig_index; H.length = alignment_length; H.n_ops = nops;
@@ -390,14 +431,35 @@ STITCH_HD void walk_from(const JobView& V, uint32_t contig_index, ChainHdr& H, O
 
 #if defined(__HIPCC__)
 // One wavefront, one walk: every lane carries the same state (walk_core.h, walk_from_t), lane 0 writes.
+// role 0: a plain walk.  role 1: the reference walk of traceback_all, which records its state on entering every column (VisitRec).
+// role 2: another walk of the same read, which stops where it enters a column in the recorded state.
 struct WaveWalk {
     int lane;
+    int role = 0; uint32_t ref_slot = 0; const ChainHdr* ref_hdr = nullptr;
+    mutable bool met = false; mutable uint32_t met_nops = 0, met_nonspecial = 0;
     __device__ bool writer() const { return lane == 0; }
+    __device__ bool joined() const { return met; }
+    __device__ uint32_t join_nops() const { return met_nops; }
+    __device__ uint32_t join_nonspecial() const { return met_nonspecial; }
+    __device__ ChainHdr reference_header() const { return *ref_hdr; }
+    __device__ static uint32_t layer_word(uint32_t layer, bool yfirst) { return layer | (yfirst ? 0x100u : 0u); }
+    __device__ bool enter_column(const JobView& V, uint32_t cur, uint32_t i, uint32_t j, uint32_t layer, uint32_t nops, uint32_t nonspecial, bool yfirst) const {
+        if (role == 1) { if (lane == 0) { VisitRec r; r.contig = (uint16_t)cur; r.row = (uint16_t)i; r.layer = layer_word(layer, yfirst); r.nops = nops; r.nonspecial = nonspecial; V.visit[j + 1] = r; } return false; }
+        if (role != 2 || yfirst) return false;
+        const VisitRec r = V.visit[j + 1];
+        if (r.contig == (uint16_t)cur && r.row == (uint16_t)i && r.layer == layer_word(layer, false)) { met = true; met_nops = r.nops; met_nonspecial = r.nonspecial; return true; }
+        return false;
+    }
+    __device__ void finish_reference(const JobView& V, uint32_t nops, uint32_t nonspecial, bool usable) const {
+        if (role != 1 || lane != 0) return;
+        VisitRec r; r.contig = (uint16_t)ref_slot; r.row = usable ? 1 : 0; r.layer = 0; r.nops = nops; r.nonspecial = nonspecial; V.visit[0] = r;
+    }
     // Cells (i-l, j-l), l = 0..63, fetched by lane l.  Returns the number L of leading cells that are plain diagonal steps
     // (traceback code MV_DIAG: source = the cell up-left in the same contig) with row >= 2 and 1 <= column < n (row 1 can
     // hold the circular jump, column n the fix-up overrides: both stay on the literal path); their operations are written
-    // by the lanes themselves.
-    __device__ uint32_t diag_run(const JobView& V, uint32_t cur, uint32_t i, uint32_t j, uint32_t nops, OpRec* ops, uint32_t ops_cap) const {
+    // by the lanes themselves.  Cell l >= 1 is where the walk enters column j - l: the reference walk records it there, another
+    // walk compares, and the run is cut at the first cell that is the reference walk's (`met`).
+    __device__ uint32_t diag_run(const JobView& V, uint32_t cur, uint32_t i, uint32_t j, uint32_t nops, OpRec* ops, uint32_t ops_cap, uint32_t nonspecial, bool yfirst) const {
         const uint32_t l = (uint32_t)lane;
         const bool inb = l + 2 <= i && l + 1 <= j && j - l < V.n;
         bool ok = false, match = false;
@@ -410,7 +472,19 @@ struct WaveWalk {
             match = V.xseq[d.seqoff + ii - 1] == V.y[jj - 1];
         }
         const unsigned long long bad = ~__ballot(ok);
-        const uint32_t L = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+        uint32_t L = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+        if (role == 2 && !yfirst && L > 1) {
+            // lane l (1 <= l < L) holds the cell through which the walk enters column j - l, in the S layer, with l operations of this run behind it
+            bool same = false; VisitRec r{};
+            if (l >= 1 && l < L) { r = V.visit[j - l + 1]; same = r.contig == (uint16_t)cur && r.row == (uint16_t)(i - l) && r.layer == layer_word(match ? TB_MATCH : TB_SUBST, false); }
+            const unsigned long long hit = __ballot(same);
+            if (hit) {
+                const int at = (int)__builtin_ctzll(hit);
+                met = true; met_nops = (uint32_t)__builtin_amdgcn_readlane((int)r.nops, at); met_nonspecial = (uint32_t)__builtin_amdgcn_readlane((int)r.nonspecial, at);
+                L = (uint32_t)at;                                   // the cells before it are this walk's own
+            }
+        }
+        if (role == 1 && l >= 1 && l < L) { VisitRec r; r.contig = (uint16_t)cur; r.row = (uint16_t)(i - l); r.layer = layer_word(match ? TB_MATCH : TB_SUBST, yfirst); r.nops = nops + l; r.nonspecial = nonspecial + l; V.visit[j - l + 1] = r; }
         if (l < L && nops + l < ops_cap) { OpRec o; o.kind = match ? OP_MATCH : OP_SUBST; o.pad = 0; o.contig = 0; o.arg = 0; ops[nops + l] = o; }
         return L;
     }
