@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads-per-step", type=int, default=320, help="reads per GPU per step (320 = eight full launches of the register-resident fill: 40 reads x 50 contigs = 2000 of the chip's 2048 wave slots; two launches are in flight, the next one taking the slots that finished reads free, and fix-up, walk and downloads of a launch run beside the fills)")
+    ap.add_argument("--reads-per-step", type=int, default=640, help="reads per GPU per step.  The register-resident fill keeps 40 teams (40 reads x 50 contigs = 2000 of the chip's 2048 wave slots) resident for the whole step; a team that ends a read pulls the next one off a queue, the host walks finished reads and recycles their arena blocks meanwhile: 640 reads = 16 reads per team")
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--contigs", type=int, default=50)
     ap.add_argument("--contig-len", type=int, default=5000)

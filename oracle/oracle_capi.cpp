@@ -170,6 +170,10 @@ int orc_al_prealign(void* hh, int32_t* score) { auto* h = (OrcAligners*)hh; if (
 long orc_banded_local_score(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match, int32_t mismatch, int32_t go, int32_t ge) {
     try { return banded_local_score(x, m, y, n, k, w, match, mismatch, go, ge); } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
+long orc_banded_score(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match, int32_t mismatch, int32_t go, int32_t ge,
+                      int32_t xp, int32_t xs, int32_t yp, int32_t ys) {
+    try { return banded_score(x, m, y, n, k, w, match, mismatch, go, ge, xp, xs, yp, ys); } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
 int orc_banded_band(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match, int32_t go, int32_t ge, uint32_t* lo, uint32_t* hi) {
     try { return banded_band(x, m, y, n, k, w, match, go, ge, lo, hi); } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }

@@ -106,48 +106,72 @@ int banded_band(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k
     return full ? 1 : 0;
 }
 
-int32_t banded_local_score(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match,
-                           int32_t mismatch, int32_t go, int32_t ge) {
+// The banded score under bio's four clip penalties (0 = free, MIN_SCORE = forbidden; x = query, y = target: the argument order of
+// custom_with_prehash(query, target, ..), aligners/mod.rs:556-566; Options::banded_scoring hands the mode's penalties over, :133-141).
+// UNPINNED like everything in this file.  What is restated is the documented meaning of the penalties ("xclip_prefix: the penalty for
+// clipping a prefix of x", likewise the other three) on the band of the local filter.  Where that is silent this repository chose:
+//   * row 0 and column 0 always belong to the band: S(0, j) = max(yclip_prefix, go + ge j), S(i, 0) = max(xclip_prefix, go + ge i),
+//     S(0, 0) = 0 (the skipped prefix is clipped or gapped);
+//   * a cell may start the alignment: xclip_prefix + S(0, j), or yclip_prefix + go + ge i;
+//   * the score is the best in-band cell plus what the rest of both sequences costs there, max(xclip_suffix, go + ge (m - i)) for i < m
+//     and max(yclip_suffix, go + ge (n - j)) for j < n — or the empty alignment, max(xp, xs, go + ge m) + max(yp, ys, go + ge n).
+// With all four penalties 0 this is step 4 of the definition at the top of the file, cell for cell (the product's fast Local kernels
+// compute that; tests/test_prealign.py compares the two forms).
+int32_t banded_score(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match, int32_t mismatch, int32_t go, int32_t ge,
+                     int32_t xp, int32_t xs, int32_t yp, int32_t ys) {
     const Band b = make_band(x, m, y, n, k, w, match, go, ge);
     auto inband = [&](size_t i, size_t j) { return i >= b.lo[j] && i < b.hi[j]; };
-    auto floor_min = [](int64_t v) { return (int32_t)std::max<int64_t>(v, MIN_SCORE); };
-    std::vector<int32_t> H[2], D[2], I(m + 1);
+    auto floor_min = [](int64_t v) { return (int64_t)std::max<int64_t>(v, MIN_SCORE); };
+    auto row0 = [&](size_t j) -> int64_t { return j == 0 ? 0 : std::max<int64_t>(yp, (int64_t)go + (int64_t)ge * (int64_t)j); };
+    auto col0 = [&](size_t i) -> int64_t { return i == 0 ? 0 : std::max<int64_t>(xp, (int64_t)go + (int64_t)ge * (int64_t)i); };
+    std::vector<int64_t> H[2], D[2], I(m + 1);
     for (int t = 0; t < 2; ++t) { H[t].assign(m + 1, MIN_SCORE); D[t].assign(m + 1, MIN_SCORE); }
-    int32_t best = 0;
+    int64_t best = std::max<int64_t>(std::max(xp, xs), m ? (int64_t)go + (int64_t)ge * (int64_t)m : 0) + std::max<int64_t>(std::max(yp, ys), n ? (int64_t)go + (int64_t)ge * (int64_t)n : 0);
     for (size_t j = 1; j <= n; ++j) {
         const int cur = (int)(j & 1), prv = 1 - cur;
+        const int64_t ry = j == n ? 0 : std::max<int64_t>(ys, (int64_t)go + (int64_t)ge * (int64_t)(n - j));
         for (size_t i = 1; i <= m; ++i) {
             if (!inband(i, j)) { H[cur][i] = MIN_SCORE; D[cur][i] = MIN_SCORE; I[i] = MIN_SCORE; continue; }
-            const int32_t hd = (i == 1 || j == 1) ? 0 : (inband(i - 1, j - 1) ? H[prv][i - 1] : MIN_SCORE);
-            const int32_t hl = j == 1 ? 0 : (inband(i, j - 1) ? H[prv][i] : MIN_SCORE), dl = (j == 1 || !inband(i, j - 1)) ? MIN_SCORE : D[prv][i];
-            const int32_t hu = i == 1 ? 0 : (inband(i - 1, j) ? H[cur][i - 1] : MIN_SCORE), iu = (i == 1 || !inband(i - 1, j)) ? MIN_SCORE : I[i - 1];
-            const int32_t d = floor_min(std::max<int64_t>((int64_t)dl + ge, (int64_t)hl + go + ge));
-            const int32_t in = floor_min(std::max<int64_t>((int64_t)iu + ge, (int64_t)hu + go + ge));
+            const int64_t hd = j == 1 ? col0(i - 1) : i == 1 ? row0(j - 1) : (inband(i - 1, j - 1) ? H[prv][i - 1] : MIN_SCORE);
+            const int64_t hl = j == 1 ? col0(i) : (inband(i, j - 1) ? H[prv][i] : MIN_SCORE), dl = (j == 1 || !inband(i, j - 1)) ? MIN_SCORE : D[prv][i];
+            const int64_t hu = i == 1 ? row0(j) : (inband(i - 1, j) ? H[cur][i - 1] : MIN_SCORE), iu = (i == 1 || !inband(i - 1, j)) ? MIN_SCORE : I[i - 1];
+            const int64_t d = floor_min(std::max(dl + ge, hl + go + ge));
+            const int64_t in = floor_min(std::max(iu + ge, hu + go + ge));
             const int32_t s = x[i - 1] == y[j - 1] ? match : mismatch;
-            int32_t h = floor_min((int64_t)hd + s);
-            h = std::max(h, d); h = std::max(h, in); h = std::max(h, 0);
+            int64_t h = floor_min(hd + s);
+            h = std::max(h, d); h = std::max(h, in);
+            h = std::max(h, floor_min((int64_t)xp + row0(j)));
+            h = std::max(h, floor_min((int64_t)yp + go + (int64_t)ge * (int64_t)i));
             H[cur][i] = h; D[cur][i] = d; I[i] = in;
-            best = std::max(best, h);
+            const int64_t rx = i == m ? 0 : std::max<int64_t>(xs, (int64_t)go + (int64_t)ge * (int64_t)(m - i));
+            if (h > MIN_SCORE) best = std::max(best, h + rx + ry);
         }
     }
-    return best;
+    return (int32_t)std::max<int64_t>(best, MIN_SCORE);
+}
+int32_t banded_local_score(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match,
+                           int32_t mismatch, int32_t go, int32_t ge) {
+    return banded_score(x, m, y, n, k, w, match, mismatch, go, ge, 0, 0, 0, 0);
 }
 
 // Aligners::align with opts.pre_align (mod.rs:237-340): the banded score of every target strand decides which contigs
 // take part; returns the chains and the largest kept score (None when nothing passed).
 std::vector<Alignment> Aligners::align_prealign(const uint8_t* read, size_t n, const std::vector<TargetSeq>& target_seqs,
                                                 std::optional<int32_t>* prealign_score) {
-    if (opts.mode != Local) throw std::runtime_error("pre-alignment is restated for local mode only (parity unpinned, see prealign_oracle.cpp)");
+    // Options::clipping (mod.rs:123-131) handed to the banded scorer (:133-141), whose x is the query
+    int32_t xp = 0, xs = 0, yp = 0, ys = 0;
+    if (opts.mode == QueryLocal || opts.mode == Global) { xp = MIN_SCORE; xs = MIN_SCORE; }
+    if (opts.mode == TargetLocal || opts.mode == Global) { yp = MIN_SCORE; ys = MIN_SCORE; }
     std::vector<uint8_t> query(read, read + n);
     for (auto& b : query) if (b >= 'a' && b <= 'z') b = (uint8_t)(b - 32);
     std::map<uint32_t, int32_t> kept;
     for (const TargetSeq& t : target_seqs) {                                     // prealign_local_banded, :575-604
-        const int32_t f = banded_local_score(query.data(), n, t.fwd.data(), t.fwd.size(), opts.kmer_size, opts.band_width, opts.match_score,
-                                             opts.mismatch_score, opts.gap_open, opts.gap_extend);
+        const int32_t f = banded_score(query.data(), n, t.fwd.data(), t.fwd.size(), opts.kmer_size, opts.band_width, opts.match_score,
+                                       opts.mismatch_score, opts.gap_open, opts.gap_extend, xp, xs, yp, ys);
         if (f >= opts.pre_align_min_score) kept[(uint32_t)*multi_contig.contig_index_for_strand(true, t.name)] = f;
         if (opts.double_strand) {
-            const int32_t r = banded_local_score(query.data(), n, t.revcomp.data(), t.revcomp.size(), opts.kmer_size, opts.band_width,
-                                                 opts.match_score, opts.mismatch_score, opts.gap_open, opts.gap_extend);
+            const int32_t r = banded_score(query.data(), n, t.revcomp.data(), t.revcomp.size(), opts.kmer_size, opts.band_width,
+                                           opts.match_score, opts.mismatch_score, opts.gap_open, opts.gap_extend, xp, xs, yp, ys);
             if (r >= opts.pre_align_min_score) kept[(uint32_t)*multi_contig.contig_index_for_strand(false, t.name)] = r;
         }
         if (!opts.pre_align_subset_contigs && !kept.empty()) break;              // :276-278

@@ -220,6 +220,8 @@ std::vector<std::string> format_sam(const Options& opts, const std::vector<Targe
                                     std::optional<int32_t> pre_alignment_score, std::string* err);
 
 // prealign_oracle.cpp: bio 1.1.0 pairwise::banded restated from its published description (parity unpinned)
+int32_t banded_score(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match, int32_t mismatch, int32_t go, int32_t ge,
+                     int32_t xclip_prefix, int32_t xclip_suffix, int32_t yclip_prefix, int32_t yclip_suffix);      // every clipping mode (x = query)
 int32_t banded_local_score(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match,
                            int32_t mismatch, int32_t go, int32_t ge);
 int banded_band(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, int32_t match, int32_t go, int32_t ge,

@@ -253,12 +253,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     const uint2 wm = wave_map[wv];
     // (tell the compiler these are uniform, so that everything read through V is scalar)
     const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)wm.x);       // classic launch: the job; persistent teams: the team
-    const uint32_t kmine = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wm.y & 0x3FFFFFFFu));      // this wave's contig: active contig number
+    const uint32_t kmine = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wm.y & 0x1FFFFFFFu));      // this wave's contig: active contig number
     // (experiment, STITCH_REGS_MAP=2) bit 30: the host has dealt this team's waves to workgroups of one XCD and asks for PLAIN granule stores:
     // they stay in that XCD's L2, where the team's sc1 polls (L1-bypassing, L2-served) find them without the trip through the fabric
     const uint32_t gran_aux = ((uint32_t)__builtin_amdgcn_readfirstlane((int)wm.y) & 0x40000000u) ? (uint32_t)AUX_VOLATILE : (uint32_t)(AUX_SC1 | AUX_VOLATILE);
-    if (kmine == 0x3FFFFFFFu) return;               // a padding entry of the wave map
+    // bit 29: the waves of this workgroup all belong to ONE team (the host sets it where every read's contigs fill whole workgroups): the
+    // workgroup's first wave polls the team's granules for all of them and hands them over through LDS.  Every wave of a team polling every
+    // granule on its own is (waves x contigs) sc1 loads per round — at cfg5's 200 contigs 3.2 MB per round over ten teams, rounds of a
+    // microsecond or two: terabytes per second at the L2s and the fabric for 1.6 KB of news per team and column.
+    const bool wg_poll = ((uint32_t)__builtin_amdgcn_readfirstlane((int)wm.y) & 0x20000000u) != 0u;
+    if (kmine == 0x1FFFFFFFu) return;               // a padding entry of the wave map
     const bool streaming = qp != nullptr;           // (the queue's words are read through qp where they are needed: two scalar registers across the column loop, not fifteen)
+    if (wg_poll) {      // (LDS comes as the last workgroup left it: no tag of this launch there before anybody looks)
+        extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn0[];
+        if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) == 0) *(volatile uint32_t*)(s_dyn0 + LDS_TB + 4096) = 0u;
+        __syncthreads();
+    }
     // ---- persistent teams: one round of this loop per read the team aligns (a classic launch leaves after the first) -----------------
     for (uint32_t seq = 1;; ++seq) {
     uint32_t job = slot;
@@ -466,7 +476,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
             const uint32_t gso = (want & 1u) * C * 8u;
             // (a spinning wave takes issue slots from the wave it shares its SIMD with, which is computing another read's column: the
             // loop is kept to a load, a compare and a sleep; the clock is looked at once in 1024 rounds)
+            // the workgroup's shared copy of the team's granules: two columns' worth (the poller fills one while its mates may still read the
+            // other: it cannot be two columns ahead of a mate, whose granule of the column between it needs), then the tag of what is there
+            unsigned long long* const wg_gran = (unsigned long long*)(s_dyn + LDS_TB) + (want & 1u) * 256u;
+            volatile uint32_t* const wg_tag = (volatile uint32_t*)(s_dyn + LDS_TB + 4096);
+            const uint32_t tag_now = (seq << 16) | (want & 0xFFFFu);
             const uint32_t t0 = (uint32_t)wall_clock64();
+            if (wg_poll && wave != 0) {
+                for (uint32_t spins = 1;; ++spins) {
+                    if (*wg_tag == tag_now) break;
+                    if ((spins & 4095u) == 0 && (uint32_t)wall_clock64() - t0 > 420000000u) {
+                        if (lane == 0) { *V.err = 1; if (streaming) __hip_atomic_store(qp->h_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+#pragma unroll
+                for (int qq = 0; qq < NQ; ++qq) gv[qq] = wg_gran[lane_p + 64 * qq];
+            }
+            else
             for (uint32_t spins = 1;; ++spins) {
                 bool ok = true;
 #pragma unroll
@@ -491,6 +519,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
                     }
                 }
                 __builtin_amdgcn_s_sleep(STITCH_POLL_SLEEP);
+            }
+            if (wg_poll && wave == 0) {      // (the poller's own granule as it wrote it, then the news for the workgroup's other waves)
+#pragma unroll
+                for (int qq = 0; qq < NQ; ++qq) { if ((uint32_t)lane_p + 64u * qq == kmine) gv[qq] = own_gran; wg_gran[lane_p + 64 * qq] = gv[qq]; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the records are in LDS before their tag
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) *wg_tag = tag_now;
             }
 #pragma unroll
             for (int qq = 0; qq < NQ; ++qq) if ((uint32_t)lane_p + 64u * qq == kmine) gv[qq] = own_gran;

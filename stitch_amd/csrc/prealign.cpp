@@ -145,15 +145,16 @@ bool make_band(const std::vector<Seed>& seeds, uint32_t m, uint32_t n, uint32_t 
     return full;
 }
 
-void rasterise_band(const std::vector<Seed>& seeds, const std::vector<uint32_t>& chain, uint32_t m, uint32_t n, uint32_t k, uint32_t w,
-                    std::vector<uint16_t>& lo, std::vector<uint16_t>& hi) {
-    lo.assign(n + 1, (uint16_t)(m + 1)); hi.assign(n + 1, 0);
-    if (chain.empty()) { std::fill(lo.begin(), lo.end(), (uint16_t)0); std::fill(hi.begin(), hi.end(), (uint16_t)(m + 1)); return; }
+template <typename R>
+static void rasterise_band_t(const std::vector<Seed>& seeds, const std::vector<uint32_t>& chain, uint32_t m, uint32_t n, uint32_t k, uint32_t w,
+                             std::vector<R>& lo, std::vector<R>& hi) {
+    lo.assign(n + 1, (R)(m + 1)); hi.assign(n + 1, 0);
+    if (chain.empty()) { std::fill(lo.begin(), lo.end(), (R)0); std::fill(hi.begin(), hi.end(), (R)(m + 1)); return; }
 
     // 3. band around the backbone: the union of the squares of half-width w around its points
     auto add = [&](long r, long c) {
         const long c0 = std::max<long>(c - (long)w, 0), c1 = std::min<long>(c + (long)w, (long)n);
-        const uint16_t r0 = (uint16_t)std::max<long>(r - (long)w, 0), r1 = (uint16_t)(std::min<long>(r + (long)w, (long)m) + 1);
+        const R r0 = (R)std::max<long>(r - (long)w, 0), r1 = (R)(std::min<long>(r + (long)w, (long)m) + 1);
         for (long cc = c0; cc <= c1; ++cc) { if (r0 < lo[cc]) lo[cc] = r0; if (r1 > hi[cc]) hi[cc] = r1; }
     };
     // the same for the points (r + t, c + t), t = 0..len, of a diagonal run, one update per column instead of one per point
@@ -164,7 +165,7 @@ void rasterise_band(const std::vector<Seed>& seeds, const std::vector<uint32_t>&
         for (long cc = c0; cc <= c1; ++cc) {
             const long t0 = std::max<long>(cc - c - (long)w, 0), t1 = std::min<long>(cc - c + (long)w, len);
             if (t0 > t1) continue;
-            const uint16_t r0 = (uint16_t)std::max<long>(r + t0 - (long)w, 0), r1 = (uint16_t)(std::min<long>(r + t1 + (long)w, (long)m) + 1);
+            const R r0 = (R)std::max<long>(r + t0 - (long)w, 0), r1 = (R)(std::min<long>(r + t1 + (long)w, (long)m) + 1);
             if (r0 < lo[cc]) lo[cc] = r0;
             if (r1 > hi[cc]) hi[cc] = r1;
         }
@@ -191,6 +192,12 @@ void rasterise_band(const std::vector<Seed>& seeds, const std::vector<uint32_t>&
     { const Seed s = seeds[chain.back()]; const long ie = (long)s.i + k, je = (long)s.j + k;
       add_diag(ie + 1, je + 1, std::min((long)m - ie, (long)n - je) - 1); }
 }
+
+void rasterise_band(const std::vector<Seed>& seeds, const std::vector<uint32_t>& chain, uint32_t m, uint32_t n, uint32_t k, uint32_t w,
+                    std::vector<uint16_t>& lo, std::vector<uint16_t>& hi) { rasterise_band_t<uint16_t>(seeds, chain, m, n, k, w, lo, hi); }
+// (reads beyond 65 534 bases: row numbers no longer fit 16 bits)
+void rasterise_band32(const std::vector<Seed>& seeds, const std::vector<uint32_t>& chain, uint32_t m, uint32_t n, uint32_t k, uint32_t w,
+                      std::vector<uint32_t>& lo, std::vector<uint32_t>& hi) { rasterise_band_t<uint32_t>(seeds, chain, m, n, k, w, lo, hi); }
 
 // the calls of rasterise_band as data (same order, same arguments)
 void band_elements(const std::vector<Seed>& seeds, const std::vector<uint32_t>& chain, uint32_t m, uint32_t n, uint32_t k, std::vector<BandElem>& out) {

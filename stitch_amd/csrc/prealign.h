@@ -62,5 +62,17 @@ struct BandPair {
 // what the band kernel finds: which score kernel takes the pair
 enum : uint32_t { BAND_CLASS_RING = 0, BAND_CLASS_TALL = 2, BAND_CLASS_WINDOW = 3 };
 struct BandScoring { int32_t match, mismatch, gap_open, gap_extend; };
+// ... with the four clip penalties of the clipping mode (0 = free, MIN_SCORE = forbidden; x = the read, rows; y = the target strand,
+// columns: the argument order of bio's custom_with_prehash(query, target, ..), aligners/mod.rs:556-566, and Options::clipping, :123-141)
+struct BandScoringClip { int32_t match, mismatch, gap_open, gap_extend, xclip_prefix, xclip_suffix, yclip_prefix, yclip_suffix; };
+// one pair of the general launch (every clipping mode, reads of any length): 32-bit band ranges, 64-bit offsets
+struct BandPair32 {
+    uint32_t m, n;
+    uint64_t q_off, t_off;         // query bases (launch buffer), target bases (context's contig buffer)
+    uint64_t band_off;             // uint32 lo[n+1] then hi[n+1]
+    uint64_t state_off;            // int32 H[2][m+1], D[m+1]
+};
+void rasterise_band32(const std::vector<Seed>& seeds, const std::vector<uint32_t>& chain, uint32_t m, uint32_t n, uint32_t k, uint32_t w,
+                      std::vector<uint32_t>& lo, std::vector<uint32_t>& hi);
 
 }  // namespace stitch

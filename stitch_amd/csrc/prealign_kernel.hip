@@ -86,6 +86,86 @@ __global__ __launch_bounds__(64) void banded_score_kernel(const BandPair* __rest
     if (lane == 0) scores[pid] = best;
 }
 
+// The banded score in EVERY clipping mode and for reads of any length (32-bit band ranges): the filter of `--pre-align` follows `--mode`
+// in the reference (Options::banded_scoring, aligners/mod.rs:133-141), and its reads have no length limit (:246-284).  Same organisation
+// as banded_score_kernel above — one wavefront per pair, columns in order, H and D of the previous column in global memory — with bio's
+// four clip penalties (0 = free, MIN_SCORE = forbidden; x = read, y = target).  PARITY UNPINNED like the local filter: crate bio 1.1.0 is not
+// in the reference tree and no reference test touches it; what is restated is the documented meaning of the penalties ("xclip_prefix:
+// the penalty for clipping a prefix of x", and so on for the other three), with the band of the local filter.  Definitions this
+// repository chose where the description is silent (the oracle, oracle/prealign_oracle.cpp, states the same): row 0 and column 0 are
+// always in the band and hold  S(0, j) = max(yclip_prefix, go + ge j),  S(i, 0) = max(xclip_prefix, go + ge i)  (the skipped prefix is
+// clipped or gapped); a cell may also start the alignment,  xclip_prefix + S(0, j)  or  yclip_prefix + go + ge i;  the score is the best
+// in-band cell plus what the rest of both sequences costs there,  max(xclip_suffix, go + ge (m - i))  for i < m and
+// max(yclip_suffix, go + ge (n - j))  for j < n, or the empty alignment  max(xp, xs, go + ge m) + max(yp, ys, go + ge n).  With all four
+// penalties 0 this is the local filter's score cell for cell.
+__global__ __launch_bounds__(64) void banded_score_general_kernel(const BandPair32* __restrict__ pairs, uint32_t n_pairs, BandScoringClip sc,
+                                                                  const uint8_t* __restrict__ reads, const uint8_t* __restrict__ contigs,
+                                                                  const uint32_t* __restrict__ bands, int32_t* __restrict__ state, int32_t* __restrict__ scores) {
+    const uint32_t pid = blockIdx.x;
+    if (pid >= n_pairs) return;
+    const BandPair32 P = pairs[pid];
+    const int lane = threadIdx.x;
+    const uint32_t m = P.m, n = P.n;
+    const uint8_t* q = reads + P.q_off; const uint8_t* t = contigs + P.t_off;
+    const uint32_t* lo = bands + P.band_off; const uint32_t* hi = lo + (n + 1);
+    int32_t* H0 = state + P.state_off; int32_t* H1 = H0 + (m + 1); int32_t* D = H1 + (m + 1);
+    const long long go = sc.gap_open, ge = sc.gap_extend;
+    const long long xp = sc.xclip_prefix, xs = sc.xclip_suffix, yp = sc.yclip_prefix, ys = sc.yclip_suffix;
+    auto row0 = [&](uint32_t j) -> long long { return j == 0 ? 0ll : max(yp, go + ge * (long long)j); };        // S(0, j)
+    auto col0 = [&](uint32_t i) -> long long { return i == 0 ? 0ll : max(xp, go + ge * (long long)i); };        // S(i, 0)
+    long long best = max(max(xp, xs), m ? go + ge * (long long)m : 0ll) + max(max(yp, ys), n ? go + ge * (long long)n : 0ll);      // nothing aligned
+    if (m == 0) best = max(best, max(max(yp, ys), n ? go + ge * (long long)n : 0ll));
+    for (uint32_t j = 1; j <= n; ++j) {
+        const uint32_t r0 = max(lo[j], 1u), r1 = min(hi[j], m + 1);
+        if (r0 >= r1) continue;
+        const uint32_t plo = lo[j - 1], phi = hi[j - 1];
+        const uint8_t tj = t[j - 1];
+        const int32_t* Hp = (j & 1) ? H0 : H1; int32_t* Hc = (j & 1) ? H1 : H0;
+        const long long s0j = row0(j), s0jm1 = row0(j - 1);
+        const long long ry = j == n ? 0ll : max(ys, go + ge * (long long)(n - j));
+        long long carry = r0 == 1 ? s0j : NO_KEY;                    // row 0 opens the column's insertion chain with S(0, j): T(0) - ge * 0
+        for (uint32_t base = r0; base < r1; base += 64) {
+            const uint32_t i = base + (uint32_t)lane;
+            const bool valid = i < r1;
+            long long T = MIN_SCORE; int32_t d = MIN_SCORE; long long key = NO_KEY;
+            if (valid) {
+                long long hd, hl, dl;
+                if (j == 1) { hd = col0(i - 1); hl = col0(i); dl = MIN_SCORE; }
+                else {
+                    hd = i == 1 ? s0jm1 : ((i - 1 >= plo && i - 1 < phi) ? (long long)Hp[i - 1] : (long long)MIN_SCORE);
+                    const bool in = i >= plo && i < phi;
+                    hl = in ? (long long)Hp[i] : (long long)MIN_SCORE; dl = in ? (long long)D[i] : (long long)MIN_SCORE;
+                }
+                d = floor_min(max(dl + ge, hl + go + ge));
+                const int32_t s = q[i - 1] == tj ? sc.match : sc.mismatch;
+                T = max((long long)floor_min(hd + s), (long long)d);
+                T = max(T, (long long)floor_min(xp + s0j));                                   // the read's first i bases clipped
+                T = max(T, (long long)floor_min(yp + go + ge * (long long)i));                // the target's first j bases clipped, the read's inserted
+                key = T - ge * (long long)i;
+            }
+            long long incl = key;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { const long long o = shfl_up_ll(incl, dd); if (lane >= dd && o > incl) incl = o; }
+            long long pre = shfl_up_ll(incl, 1); if (lane == 0) pre = NO_KEY;
+            if (carry > pre) pre = carry;
+            if (valid) {
+                const int32_t I = pre == NO_KEY ? MIN_SCORE : floor_min(pre + go + ge * (long long)i);
+                const int32_t h = (int32_t)max(T, (long long)I);
+                Hc[i] = h; D[i] = d;
+                const long long rx = i == m ? 0ll : max(xs, go + ge * (long long)(m - i));
+                if (h > MIN_SCORE) best = max(best, (long long)h + rx + ry);
+            }
+            const int lo32 = __shfl((int)(unsigned)(unsigned long long)incl, 63, 64), hi32 = __shfl((int)(unsigned)((unsigned long long)incl >> 32), 63, 64);
+            const long long tail = (long long)(((unsigned long long)(unsigned)hi32 << 32) | (unsigned)lo32);
+            if (tail > carry) carry = tail;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) { const long long o = (long long)(((unsigned long long)(unsigned)__shfl_xor((int)(unsigned)((unsigned long long)best >> 32), dd, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)(unsigned long long)best, dd, 64)); best = max(best, o); }
+    if (lane == 0) scores[pid] = floor_min(best);
+}
+
 // The same recurrence with the column state on chip: H (two columns) and D live in LDS rings of BAND_RING rows indexed by
 // row mod BAND_RING, which holds any band whose columns are at most BAND_RING rows tall (the host sends taller ones to
 // the kernel above); the read's bases are staged in LDS once; the band ranges and target bases of 64 columns are
@@ -327,6 +407,10 @@ uint32_t full_score_max_rows() { return FULL_MAX_ROWS; }
 void launch_banded_scores(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, const BandScoring& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
                           const uint16_t* d_bands, int32_t* d_state, int32_t* d_scores, const uint32_t* d_cls, uint32_t my_class, hipStream_t stream) {
     if (n_pairs) hipLaunchKernelGGL(banded_score_kernel, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_which, sc, d_reads, d_contigs, d_bands, d_state, d_scores, d_cls, my_class);
+}
+void launch_banded_scores_general(const BandPair32* d_pairs, uint32_t n_pairs, const BandScoringClip& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
+                                  const uint32_t* d_bands, int32_t* d_state, int32_t* d_scores, hipStream_t stream) {
+    if (n_pairs) hipLaunchKernelGGL(banded_score_general_kernel, dim3(n_pairs), dim3(64), 0, stream, d_pairs, n_pairs, sc, d_reads, d_contigs, d_bands, d_state, d_scores);
 }
 // pairs whose band columns are at most banded_ring_rows() tall and whose reads are at most max_m long; false = not applicable
 // (scores or keys do not fit 32 bits, or the read does not fit in LDS): the caller uses launch_banded_scores for them too

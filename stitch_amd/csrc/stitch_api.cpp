@@ -39,6 +39,8 @@ uint32_t full_score_max_rows();
 bool launch_full_scores_skew16(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_full, uint32_t max_m, uint32_t max_n, const BandScoring& sc,
                                const uint8_t* d_reads, const uint8_t* d_contigs, int32_t* d_scores, hipStream_t stream);
 uint32_t band_device_max_cols();
+void launch_banded_scores_general(const BandPair32* d_pairs, uint32_t n_pairs, const BandScoringClip& sc, const uint8_t* d_reads, const uint8_t* d_contigs,
+                                  const uint32_t* d_bands, int32_t* d_state, int32_t* d_scores, hipStream_t stream);
 void launch_band_draw(const BandPair* d_pairs, const uint32_t* d_which, uint32_t n_pairs, uint32_t max_n, const BandElem* d_elems, uint32_t w, uint32_t ring_rows,
                       bool window, uint16_t* d_bands, uint32_t* d_cls, uint32_t* d_class_counts, hipStream_t stream);
 bool band_fits_window(const uint16_t* lo, const uint16_t* hi, uint32_t m, uint32_t n);
@@ -96,7 +98,7 @@ struct Knobs {
     size_t array_align = 0, job_align = 0;
     std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
-    int regs_waves = 0, regs_map = 0; bool trace = false, no_stream = false, no_join = false; int stream_blocks = 0, stream_teams = 0, stream_range = 0;      // (experiments) waves per workgroup of fill_regs.hip, order of its wave map; launch timeline on stderr
+    int regs_waves = 0, regs_map = 0; bool trace = false, no_stream = false, no_join = false, no_wg_poll = false, prealign_general = false; int stream_blocks = 0, stream_teams = 0, stream_range = 0;      // (experiments) waves per workgroup of fill_regs.hip, order of its wave map; launch timeline on stderr
     static Knobs from_env() {
         Knobs k;
         auto num = [](const char* name) -> unsigned long long { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : 0ull; };
@@ -115,6 +117,8 @@ struct Knobs {
         k.array_align = (size_t)num("STITCH_ARRAY_ALIGN"); k.job_align = (size_t)num("STITCH_JOB_ALIGN");
         k.max_waves = (int)num("STITCH_MAX_WAVES"); k.wg_per_read = (int)num("STITCH_WG_PER_READ"); k.tiles_per_wave = (int)num("STITCH_TILES_PER_WAVE");
         k.regs_waves = (int)num("STITCH_REGS_WAVES"); k.regs_map = (int)num("STITCH_REGS_MAP"); k.trace = getenv("STITCH_TRACE") != nullptr;
+        k.no_wg_poll = getenv("STITCH_NO_WG_POLL") != nullptr;    // every wave polls its team's granules itself even where a workgroup's waves are one team's (A/B runs)
+        k.prealign_general = getenv("STITCH_PREALIGN_GENERAL") != nullptr;      // (tests) the filter's general path (every mode, 32-bit band ranges) also where the fast Local path applies
         k.no_join = getenv("STITCH_NO_JOIN") != nullptr;          // traceback_all: every chain walked to its start (A/B runs, tests), none joined to the reference chain
         k.no_stream = getenv("STITCH_NO_STREAM") != nullptr;      // launch by launch even where persistent teams apply (A/B runs, tests)
         k.stream_blocks = (int)num("STITCH_STREAM_BLOCKS");       // (tests) cap on the arena blocks of a persistent-team run
@@ -284,7 +288,6 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     if (o->gap_open > 0) return fail(STITCH_EINVAL, "gap_open can't be positive");
     if (o->gap_extend > 0) return fail(STITCH_EINVAL, "gap_extend can't be positive");
     if (o->jump_same > 0 || o->jump_opposite > 0 || o->jump_inter > 0) return fail(STITCH_EINVAL, "jump scores can't be positive");
-    if (o->pre_align && o->mode != 0) return fail(STITCH_EINVAL, "pre_align is implemented for local mode only (bio's banded aligner is restated from its published description, see DESIGN.md A15)");
     if (o->pre_align && (o->kmer_size < 1 || o->band_width < 0)) return fail(STITCH_EINVAL, "bad k-mer size or band width");
     const uint32_t T = (uint32_t)idx->names.size();
     const uint32_t C = T * (o->double_strand ? 2u : 1u);
@@ -771,7 +774,11 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
             wave_map[wg * c.regs_waves + sl % c.regs_waves] = make_uint2((uint32_t)t, (uint32_t)(sl % W) | (getenv("STITCH_EXP_PLAIN_GRANULES") ? 0x40000000u : 0u));
         }
     }
-    else for (uint32_t t = 0; t < (uint32_t)T; ++t) for (uint32_t k = 0; k < W; ++k) wave_map.push_back(make_uint2(t, k));
+    else {
+        // (where a team's waves fill whole workgroups, a workgroup's first wave polls the granules for all of them: bit 29, fill_regs.hip)
+        const uint32_t wgp = (W % c.regs_waves == 0 && !kn.no_wg_poll) ? 0x20000000u : 0u;
+        for (uint32_t t = 0; t < (uint32_t)T; ++t) for (uint32_t k = 0; k < W; ++k) wave_map.push_back(make_uint2(t, k | wgp));
+    }
     StreamCtl ctl{}; ctl.next = d_next; ctl.cnt = d_cnt; ctl.mbox = d_mbox; ctl.n_jobs = (uint32_t)N;
     ctl.h_ready = c.pin_q + 0; ctl.h_abort = c.pin_q + 16; ctl.h_err = c.pin_q + 32; ctl.h_done = c.pin_q + 64;
     HIP_TRY(hipMemcpyAsync(d_in, c.pin_h2d, in_total, hipMemcpyHostToDevice, sB));
@@ -1138,7 +1145,9 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         JobView* d_views = (JobView*)tail; tail += align_up(sizeof(JobView) * nj, 256);
         WalkArgs* d_wargs = (WalkArgs*)tail; tail += align_up(sizeof(WalkArgs) * nj, 256);
         std::vector<uint2> wave_map;                     // fill_regs.hip: wave of the grid -> (read of the launch, active contig)
-        if (regs_G || regs32_G) for (uint32_t q = 0; q < nj; ++q) for (uint32_t k = 0; k < lay[k0 + q].nact; ++k) wave_map.push_back(make_uint2(q, k));
+        uint32_t wgp = (regs_G && !c.knobs.no_wg_poll) ? 0x20000000u : 0u;      // fill_regs.hip: one poller per workgroup where every read's contigs fill whole workgroups
+        for (uint32_t q = 0; q < nj; ++q) if (lay[k0 + q].nact % c.regs_waves != 0) wgp = 0u;
+        if (regs_G || regs32_G) for (uint32_t q = 0; q < nj; ++q) for (uint32_t k = 0; k < lay[k0 + q].nact; ++k) wave_map.push_back(make_uint2(q, k | wgp));
         if (regs_G && c.knobs.regs_map == 1 && c.regs_waves == 8 && wave_map.size() >= 16) {
             // (experiment) eight-wave workgroups whose two waves per SIMD (waves t and t + 4) come from reads half a launch apart, as
             // two four-wave workgroups of one CU do; entries without a wave carry a contig number no read has
@@ -1386,7 +1395,124 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
 
 // The pre-alignment filter of Aligners::align (mod.rs:246-295): banded local score of every (read, target strand) pair on the
 // device, then the reference's keep / early-break / subset logic on the host.  Sets jobs[k].act and the xs score.
+
+// the reference's keep / early-break / subset rules on the banded scores of every (read, contig-strand) pair (mod.rs:246-295)
+static void prealign_apply_rules(stitch_ctx& c, std::vector<Job>& jobs, const std::vector<int32_t>& sco, std::vector<uint8_t>& has, std::vector<int32_t>& score) {
+    const uint32_t C = c.C, T = c.T; const size_t NJ = jobs.size();
+    for (size_t q = 0; q < NJ; ++q) {
+        Job& jb = jobs[q];
+        std::vector<uint32_t> kept; int32_t best = 0; bool any = false;
+        for (uint32_t t = 0; t < T; ++t) {                                     // targets in order, forward then reverse complement (:249-279)
+            const int32_t f = sco[q * C + t];
+            if (f >= c.opts.pre_align_min_score) { kept.push_back(t); best = any ? std::max(best, f) : f; any = true; }
+            if (c.opts.double_strand) {
+                const int32_t r = sco[q * C + T + t];
+                if (r >= c.opts.pre_align_min_score) { kept.push_back(T + t); best = any ? std::max(best, r) : r; any = true; }
+            }
+            if (!c.opts.pre_align_subset_contigs && any) break;                // :276-278
+        }
+        has[q] = any ? 1 : 0; score[q] = best;
+        if (any && c.opts.pre_align_subset_contigs) { std::sort(kept.begin(), kept.end()); jb.act = kept; }
+    }
+}
+
+// The filter where the fast path does not apply: a clipping mode other than Local (the reference's banded scorer takes the mode's
+// clip penalties, Options::banded_scoring, mod.rs:133-141) or a read beyond 65 534 bases (the fast path's 16-bit band ranges).  Seeds,
+// backbone and band on host threads as there, the band as 32-bit ranges, every pair — also those without a seed, whose band is the whole
+// matrix — through banded_score_general_kernel (prealign_kernel.hip), a chunk of reads at a time.  Plain and unhurried: cfg3 is Local.
+static int run_prealign_general(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& has, std::vector<int32_t>& score) {
+    HIP_TRY(hipSetDevice(c.device));
+    hipStream_t const PS = c.pstream[0];
+    const uint32_t C = c.C;
+    const size_t NJ = jobs.size(), NP = NJ * C;
+    int32_t xp = 0, xs = 0, yp = 0, ys = 0;                                    // Options::clipping (mod.rs:123-131) in bio's argument order: x = the read
+    if (c.opts.mode == 1 || c.opts.mode == 3) { xp = MIN_SCORE; xs = MIN_SCORE; }
+    if (c.opts.mode == 2 || c.opts.mode == 3) { yp = MIN_SCORE; ys = MIN_SCORE; }
+    const BandScoringClip sc{c.opts.match_score, c.opts.mismatch_score, c.opts.gap_open, c.opts.gap_extend, xp, xs, yp, ys};
+    has.assign(NJ, 0); score.assign(NJ, 0);
+    if (jobs.empty()) return STITCH_OK;
+    auto al256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    std::vector<int32_t> sco(NP, 0);
+    auto t_dev0 = std::chrono::steady_clock::now();
+    size_t per_read_bands = 0; for (uint32_t a = 0; a < C; ++a) per_read_bands += 2ull * (c.al[a].m + 1);
+    for (size_t k0 = 0; k0 < NJ;) {
+        // as many reads as the scratch holds: bases, pairs, scores, bands, three int32 of state per row and pair
+        size_t k1 = k0, bytes = 4096;
+        while (k1 < NJ) {
+            const size_t m = jobs[k1].y.size();
+            const size_t need = al256(m + 8) + (size_t)C * (sizeof(BandPair32) + 4) + 4ull * per_read_bands + (size_t)C * 12ull * (m + 1) + 1024;
+            if (bytes + need > c.pre_bytes) break;
+            bytes += need; ++k1;
+        }
+        if (k1 == k0) return fail(STITCH_ENOMEM, "pre_align: one read does not fit in the pre-alignment scratch (STITCH_PREALIGN_BYTES)");
+        const size_t nj = k1 - k0, np = nj * C;
+        std::vector<uint8_t> h_reads; std::vector<uint64_t> q_at(nj);
+        for (size_t q = 0; q < nj; ++q) { q_at[q] = h_reads.size(); h_reads.insert(h_reads.end(), jobs[k0 + q].y.begin(), jobs[k0 + q].y.end()); }
+        h_reads.resize(h_reads.size() + 8, 0);
+        std::vector<BandPair32> pairs(np);
+        std::vector<uint32_t> bands(nj * per_read_bands);
+        size_t state_elems = 0;
+        std::vector<uint64_t> a_off(C + 1, 0);
+        for (uint32_t a = 0; a < C; ++a) a_off[a + 1] = a_off[a] + 2ull * (c.al[a].m + 1);
+        for (size_t q = 0; q < nj; ++q) for (uint32_t a = 0; a < C; ++a) {
+            BandPair32& P = pairs[q * C + a]; const uint32_t m = (uint32_t)jobs[k0 + q].y.size();
+            P.m = m; P.n = c.al[a].m; P.q_off = q_at[q]; P.t_off = c.al[a].seqoff; P.band_off = q * per_read_bands + a_off[a]; P.state_off = state_elems;
+            state_elems += 3ull * (m + 1);
+        }
+        {
+            auto t_h0 = std::chrono::steady_clock::now();
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({nj, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16}));
+            std::atomic<size_t> next{0}; std::atomic<bool> failed{false};
+            auto work = [&]() {
+                try {
+                    std::vector<uint32_t> lo_, hi_, chain_; std::vector<std::vector<Seed>> seeds_;
+                    for (;;) {
+                        const size_t q = next.fetch_add(1); if (q >= nj) break;
+                        const Job& jb = jobs[k0 + q]; const uint32_t m = (uint32_t)jb.y.size();
+                        find_seeds(c.kidx, c.h_xseq.data(), c.strands, jb.y.data(), m, seeds_);
+                        for (uint32_t a = 0; a < C; ++a) {
+                            backbone_chain(seeds_[a], (uint32_t)c.opts.kmer_size, c.opts.match_score, c.opts.gap_open, c.opts.gap_extend, chain_);      // (empty: the whole matrix)
+                            rasterise_band32(seeds_[a], chain_, m, c.al[a].m, (uint32_t)c.opts.kmer_size, (uint32_t)c.opts.band_width, lo_, hi_);
+                            const BandPair32& P = pairs[q * C + a];
+                            memcpy(bands.data() + P.band_off, lo_.data(), 4ull * (P.n + 1)); memcpy(bands.data() + P.band_off + P.n + 1, hi_.data(), 4ull * (P.n + 1));
+                        }
+                    }
+                } catch (...) { failed.store(true); next.store(nj); }
+            };
+            struct Joiner { std::vector<std::thread> pool; ~Joiner() { for (auto& th : pool) if (th.joinable()) th.join(); } } J;
+            for (unsigned t = 1; t < nt; ++t) J.pool.emplace_back(work);
+            work();
+            for (auto& th : J.pool) th.join();
+            if (failed.load()) return fail(STITCH_ENOMEM, "pre_align: out of host memory while building the bands");
+            c.tm.prealign_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
+        }
+        uint8_t* p = c.pre_buf;
+        uint8_t* d_reads = p; p += al256(h_reads.size());
+        BandPair32* d_pairs = (BandPair32*)p; p += al256(np * sizeof(BandPair32));
+        int32_t* d_scores = (int32_t*)p; p += al256(np * 4);
+        uint32_t* d_bands = (uint32_t*)p; p += al256(bands.size() * 4);
+        int32_t* d_state = (int32_t*)p; p += al256(state_elems * 4);
+        if ((size_t)(p - c.pre_buf) > c.pre_bytes) return fail(STITCH_EINTERNAL, "pre-alignment scratch overflow");
+        HIP_TRY(hipMemcpyAsync(d_reads, h_reads.data(), h_reads.size(), hipMemcpyHostToDevice, PS));
+        HIP_TRY(hipMemcpyAsync(d_pairs, pairs.data(), np * sizeof(BandPair32), hipMemcpyHostToDevice, PS));
+        HIP_TRY(hipMemcpyAsync(d_bands, bands.data(), bands.size() * 4, hipMemcpyHostToDevice, PS));
+        launch_banded_scores_general(d_pairs, (uint32_t)np, sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, PS);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(sco.data() + k0 * C, d_scores, np * 4, hipMemcpyDeviceToHost, PS));
+        HIP_TRY(hipStreamSynchronize(PS));
+        k0 = k1;
+    }
+    c.tm.prealign_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev0).count();
+    prealign_apply_rules(c, jobs, sco, has, score);
+    return STITCH_OK;
+}
+
 int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& has, std::vector<int32_t>& score) {
+    {   // (other clipping modes, reads beyond the 16-bit band ranges: the general path)
+        bool general = c.opts.mode != 0;
+        for (const Job& jb : jobs) if (jb.y.size() > 65534) general = true;
+        if (general || c.knobs.prealign_general) return run_prealign_general(c, jobs, has, score);
+    }
     HIP_TRY(hipSetDevice(c.device));
     // the filter's own streams: a call's later groups of reads are filtered while the jump DP of the earlier ones runs (stitch_align_batch)
     hipStream_t const PS0 = c.pstream[0], PS1 = c.pstream[1], PS2 = c.pstream[2];      // reads + full-matrix kernels; band and banded score kernels; uploads
@@ -1657,21 +1783,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
     for (size_t k = 0; k < f_gid.size(); ++k) sco[f_gid[k]] = fsco[k];
     c.tm.prealign_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev0).count();
 
-    for (size_t q = 0; q < NJ; ++q) {
-        Job& jb = jobs[q];
-        std::vector<uint32_t> kept; int32_t best = 0; bool any = false;
-        for (uint32_t t = 0; t < T; ++t) {                                     // targets in order, forward then reverse complement (:249-279)
-            const int32_t f = sco[q * C + t];
-            if (f >= c.opts.pre_align_min_score) { kept.push_back(t); best = any ? std::max(best, f) : f; any = true; }
-            if (c.opts.double_strand) {
-                const int32_t r = sco[q * C + T + t];
-                if (r >= c.opts.pre_align_min_score) { kept.push_back(T + t); best = any ? std::max(best, r) : r; any = true; }
-            }
-            if (!c.opts.pre_align_subset_contigs && any) break;                // :276-278
-        }
-        has[q] = any ? 1 : 0; score[q] = best;
-        if (any && c.opts.pre_align_subset_contigs) { std::sort(kept.begin(), kept.end()); jb.act = kept; }
-    }
+    prealign_apply_rules(c, jobs, sco, has, score);
     return STITCH_OK;
 }
 

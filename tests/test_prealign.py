@@ -93,8 +93,9 @@ def test_oracle_aligners_prealign_logic():
     o2 = orc.Aligners(targets, pre_align=True, pre_align_min_score=60, pre_align_subset_contigs=False, kmer_size=10, band_width=20)
     o3 = orc.Aligners(targets)
     assert [c.key() for c in o2.align(read)] == [c.key() for c in o3.align(read)]
-    with pytest.raises(RuntimeError):
-        orc.Aligners(targets, pre_align=True, mode="global").align(read)
+    # (round 4: every clipping mode is restated; in global mode the read must cover a whole target: this one does not reach the threshold)
+    og = orc.Aligners(targets, pre_align=True, mode="global", pre_align_min_score=60, kmer_size=10, band_width=20)
+    assert og.align(read) == [] and og.prealign_score() is None
 
 
 def _bands(x, y, k, w, match=1, go=-6, ge=-2):
@@ -224,6 +225,78 @@ def test_device_band_equals_oracle_band():
     assert n_window > 100 and n_other > 5
 
 
+
+def banded_mode(x, y, mode, k=12, w=50, match=1, mismatch=-4, go=-6, ge=-2):
+    """the oracle's banded score under the clip penalties of a clipping mode (x = the query: Options::banded_scoring, mod.rs:133-141)"""
+    L = orc.lib()
+    L.orc_banded_score.restype = C.c_long
+    MIN = orc.MIN_SCORE
+    xp = xs = MIN if mode in ("query-local", "global") else 0
+    yp = ys = MIN if mode in ("target-local", "global") else 0
+    xb = (C.c_uint8 * max(1, len(x))).from_buffer_copy((x or "\0").encode())
+    yb = (C.c_uint8 * max(1, len(y))).from_buffer_copy((y or "\0").encode())
+    return L.orc_banded_score(xb, C.c_size_t(len(x)), yb, C.c_size_t(len(y)), C.c_size_t(k), C.c_size_t(w), match, mismatch, go, ge, xp, xs, yp, ys)
+
+
+def gotoh_mode(x, y, mode, match=1, mismatch=-4, go=-6, ge=-2):
+    """band-free affine-gap score with end gaps free on the sequence a mode clips freely: written independently of the oracle's
+    formulation (explicit start / end states instead of clip candidates)"""
+    NEG = -10**12
+    free_x = mode in ("local", "target-local")      # the query may be clipped
+    free_y = mode in ("local", "query-local")       # the target may be clipped
+    m, n = len(x), len(y)
+    gap = lambda k: 0 if k == 0 else go + ge * k
+    H = [[NEG] * (n + 1) for _ in range(m + 1)]; E = [[NEG] * (n + 1) for _ in range(m + 1)]; F = [[NEG] * (n + 1) for _ in range(m + 1)]
+    for i in range(m + 1):
+        for j in range(n + 1):
+            if i == 0 and j == 0:
+                H[i][j] = 0
+                continue
+            start = (0 if (free_x or i == 0) else gap(i)) + (0 if (free_y or j == 0) else gap(j))      # everything before (i, j) skipped
+            best = start if ((free_x or i == 0) or (free_y or j == 0) or True) else NEG
+            if i > 0:
+                F[i][j] = max(F[i - 1][j] + ge, H[i - 1][j] + go + ge); best = max(best, F[i][j])
+            if j > 0:
+                E[i][j] = max(E[i][j - 1] + ge, H[i][j - 1] + go + ge); best = max(best, E[i][j])
+            if i > 0 and j > 0:
+                best = max(best, H[i - 1][j - 1] + (match if x[i - 1] == y[j - 1] else mismatch))
+            H[i][j] = best
+    out = NEG
+    for i in range(m + 1):
+        for j in range(n + 1):
+            tail = (0 if (free_x or i == m) else gap(m - i)) + (0 if (free_y or j == n) else gap(n - j))
+            out = max(out, H[i][j] + tail)
+    return out
+
+
+def test_clipping_modes_known_answers():
+    """the general banded score (every clipping mode): with the band covering the whole matrix (no k-mer fits) it is the band-free
+    score of the mode, written twice; known small cases by hand"""
+    rng = random.Random(11)
+    # by hand: query ACGT inside target TTACGTTT.  local / query-local: 4 matches = 4.  target-local: the target's other four bases
+    # must be gapped: 4 + (go + 2 ge) * 2 = 4 - 20 = -16 ... or align nothing of the query and delete the whole target: go + 8 ge = -22.
+    assert banded_mode("ACGT", "TTACGTTT", "local", k=12) == 4
+    assert banded_mode("ACGT", "TTACGTTT", "query-local", k=12) == 4
+    assert banded_mode("ACGT", "TTACGTTT", "target-local", k=12) == gotoh_mode("ACGT", "TTACGTTT", "target-local") == -16
+    assert banded_mode("ACGT", "TTACGTTT", "global", k=12) == gotoh_mode("ACGT", "TTACGTTT", "global") == -16
+    assert banded_mode("ACGTACGT", "ACGAACGT", "global", k=12) == 7 - 4                     # one substitution
+    assert banded_mode("", "ACG", "global") == -12 and banded_mode("ACG", "", "query-local") == -12 and banded_mode("ACG", "", "target-local") == 0
+    for trial in range(30):
+        x = rnd(rng, rng.randint(1, 40)); y = rnd(rng, rng.randint(1, 40))
+        if trial % 3 == 0:
+            y = y[:10] + x + y[10:]
+        for mode in ("local", "query-local", "target-local", "global"):
+            assert banded_mode(x, y, mode, k=60) == gotoh_mode(x, y, mode), (x, y, mode)
+    # local is the old definition
+    for trial in range(10):
+        y = rnd(rng, 300); x = mutate(rng, y[40:260])
+        assert banded_mode(x, y, "local", k=8, w=20) == banded(x, y, k=8, w=20)
+    # a band that covers the path: the banded score is the band-free one; a band that does not: never above it
+    y = rnd(rng, 500); x = mutate(rng, y[100:420], 0.02, 0.01, 0.01)
+    for mode in ("query-local", "target-local", "global"):
+        assert banded_mode(x, y, mode, k=8, w=40) == gotoh_mode(x, y, mode)
+        assert banded_mode(x, y, mode, k=8, w=0) <= gotoh_mode(x, y, mode)
+
 # ---- product vs oracle ---------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("opts", [dict(), dict(double_strand=True), dict(pre_align_subset_contigs=False, double_strand=True),
@@ -301,3 +374,72 @@ def test_banded_kernels_agree_ring_tall_and_global(monkeypatch):
                 monkeypatch.delenv("STITCH_BANDED_GLOBAL", raising=False)
             al = stitch_amd.Builder(**kw).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in targets], device=0)
             assert [g[1] for g in al.align(reads)] == want, (w, env)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["query-local", "target-local", "global"])
+def test_prealign_in_the_other_clipping_modes_matches_oracle(mode):
+    """`--pre-align` with `--mode`: the reference hands the mode's clip penalties to the banded scorer (Options::banded_scoring,
+    mod.rs:133-141).  Scores of the general kernel against the oracle's, then kept contigs and chains (parity UNPINNED: both sides
+    restate bio's documented penalties)."""
+    import stitch_amd
+    rng = random.Random(31)
+    targets = [("a", rnd(rng, 260)), ("b", rnd(rng, 180)), ("c", rnd(rng, 220))]
+    reads = [mutate(rng, targets[0][1][20:240]), mutate(rng, targets[1][1]), targets[2][1][5:215], rnd(rng, 120),
+             mutate(rng, targets[0][1]) , targets[1][1][:170]]
+    kw = dict(mode=mode, pre_align=True, pre_align_min_score=-400, kmer_size=8, band_width=15, double_strand=True)
+    o = orc.Aligners(targets, **kw)
+    al = stitch_amd.Builder(**kw).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in targets], device=0)
+    try:
+        got = al.align(reads)
+    except stitch_amd.StitchError as e:
+        assert "shorter contig" in str(e)          # (the reference-undefined end-of-read jump of these modes: DESIGN.md 2)
+        pytest.skip("reference-undefined XJUMP case")
+    for k, read in enumerate(reads):
+        try:
+            want = o.align(read)
+        except RuntimeError as e:
+            assert "out of range" in str(e)
+            pytest.skip("reference-undefined XJUMP case (oracle)")
+        assert got[k][1] == o.prealign_score(), (mode, k, got[k][1], o.prealign_score())
+        assert [c.key() for c in got[k][0]] == [c.key() for c in want], (mode, k)
+    # the scores alone, pair by pair (one target, threshold below everything: the reported score is the pair's)
+    for tname, tseq in targets:
+        for read in reads:
+            kw1 = dict(mode=mode, pre_align=True, pre_align_min_score=-10**6, kmer_size=8, band_width=15)
+            al1 = stitch_amd.Builder(**kw1).build_aligners([stitch_amd.TargetSeq(tname, tseq)], device=0)
+            try:
+                sc = al1.align([read])[0][1]
+            except stitch_amd.StitchError:
+                continue
+            assert sc == banded_mode(read, tseq, mode, k=8, w=15), (mode, tname)
+
+
+@pytest.mark.gpu
+def test_prealign_general_path_equals_the_fast_path_in_local_mode(monkeypatch):
+    """STITCH_PREALIGN_GENERAL=1 sends a Local run through the general kernel (32-bit band ranges, clip penalties all zero): same
+    scores, kept contigs and chains as the fast kernels and as the oracle"""
+    import stitch_amd
+    from stitch_amd import synth
+    db = synth.make_db(5, 600, 5)
+    targets = [(n, s.decode()) for n, s in db]
+    reads = [r.decode() for r in synth.make_reads(db, 10, 350, 8, both_strands=True, random_frac=0.3)]
+    kw = dict(pre_align=True, pre_align_min_score=50, kmer_size=10, band_width=25, double_strand=True)
+    fast = stitch_amd.Builder(**kw).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in targets], device=0).align(reads)
+    monkeypatch.setenv("STITCH_PREALIGN_GENERAL", "1")
+    gen = stitch_amd.Builder(**kw).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in targets], device=0).align(reads)
+    assert [(g[1], [c.key() for c in g[0]]) for g in gen] == [(f[1], [c.key() for c in f[0]]) for f in fast]
+
+
+@pytest.mark.gpu
+def test_prealign_of_a_read_beyond_65534_bases():
+    """the fast path's band ranges are 16-bit; a longer read takes the general path (32-bit ranges) instead of being refused"""
+    import stitch_amd
+    rng = random.Random(41)
+    t = rnd(rng, 900)
+    read = rnd(rng, 33000) + mutate(rng, t[100:800]) + rnd(rng, 33000)
+    kw = dict(pre_align=True, pre_align_min_score=100, kmer_size=12, band_width=30)
+    al = stitch_amd.Builder(**kw).build_aligners([stitch_amd.TargetSeq("t", t)], device=0)
+    got = al.align([read])
+    assert len(read) > 65534 and got[0][1] == banded(read, t, k=12, w=30) and got[0][1] >= 300
+    assert got[0][0] and got[0][0][0].score >= 300
