@@ -32,7 +32,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -194,7 +199,7 @@ struct BamEncoder {
 
 // ---- arguments --------------------------------------------------------------------------------------------------
 struct Args {
-    std::string reads_fastq, reads_fasta, ref_fasta, out_format = "sam", convert_sam;
+    std::string reads_fastq, reads_fasta, ref_fasta, out_format = "bam", convert_sam;      // (the reference writes BAM to stdout, commands/align.rs:393-416)
     stitch_opts o; int jump_score = -10; bool js_same = false, js_opp = false, js_inter = false;
     int threads = 2, compression = 0, device = 0; uint32_t batch = 1024; bool decompress = false, dry_run = false;
     std::vector<int> devices;                       // --devices: one worker process per entry
@@ -225,7 +230,7 @@ const char* USAGE =
     "      --filter-secondary      --filter-secondary-pct X (10)\n"
     "      --suboptimal            --suboptimal-pct X (20)\n"
     "  -c, --compression N         BGZF level of the BAM output (0)\n"
-    "      --output-format FMT     sam (default) | bam\n"
+    "      --output-format FMT     bam (default, as the reference: BGZF level -c) | sam\n"
     "      --device N  --batch N   GPU ordinal (0), reads per library call (1024)\n"
     "      --devices A,B,...       one worker process per listed GPU; reads are cut into contiguous blocks at read-group\n"
     "                              boundaries, the output is the single-device output (a read FILE is needed, not stdin)\n"
@@ -494,40 +499,90 @@ int main(int argc, char** argv) {
     stitch_ctx* ctx = nullptr;
     if (stitch_ctx_create(a.device, index, &a.o, &ctx) != STITCH_OK) die(stitch_last_error());
 
-    std::vector<Rec> batch; std::vector<char> text(1 << 20);
+    // Three stages side by side, as the reference runs reader, aligners and writer concurrently (commands/align.rs:338-441): a reader thread
+    // parses the next batches, this thread hands batch k to the device, a writer thread formats and writes batch k - 1.  The library's
+    // result arrays live until the next stitch_align_batch, so the writer works on a copy of them through stitch_format_sam_chains (the
+    // same formatter on caller-supplied chains); output order = input order (one writer, batches in sequence).
+    struct Work { std::vector<Rec> recs; std::vector<stitch_read_result> rr; std::vector<stitch_chain> ch; std::vector<stitch_op> ops; };
+    struct Chan {                                       // a bounded queue of batches between two stages
+        std::mutex mu; std::condition_variable cv; std::deque<Work> q; bool closed = false; size_t cap = 2;
+        void push(Work&& w) { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return q.size() < cap; }); q.push_back(std::move(w)); cv.notify_all(); }
+        bool pop(Work& w) { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; w = std::move(q.front()); q.pop_front(); cv.notify_all(); return true; }
+        void close() { std::lock_guard<std::mutex> l(mu); closed = true; cv.notify_all(); }
+    } to_align, to_write;
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     uint64_t n_reads = 0, cells_total = 0;
-    auto run_batch = [&]() {
-        if (batch.empty()) return;
-        std::string cat; std::vector<uint64_t> offs(batch.size() + 1, 0);
-        for (size_t k = 0; k < batch.size(); ++k) { cat += batch[k].seq; offs[k + 1] = cat.size(); }
-        const stitch_read_result* rr; const stitch_chain* ch; const stitch_op* ops; uint64_t cells = 0;
-        if (stitch_align_batch(ctx, (const uint8_t*)cat.data(), offs.data(), (uint32_t)batch.size(), &rr, &ch, &ops, &cells) != STITCH_OK) die(stitch_last_error());
-        cells_total += cells;
-        for (size_t k = 0; k < batch.size(); ++k) {
-            const Rec& r = batch[k];
-            long len;
-            for (;;) {
-                len = stitch_format_sam(ctx, (uint32_t)k, r.head.c_str(), (const uint8_t*)r.seq.data(), r.has_qual ? (const uint8_t*)r.qual.data() : nullptr, r.seq.size(), text.data(), text.size());
-                if (len < 0) die(stitch_last_error());
-                if ((size_t)len < text.size()) break;
-                text.resize((size_t)len + 1);
-            }
-            if (!out.bam) { out.put(text.data(), (size_t)len); if (len) out.put("\n", 1); }
-            else { size_t p = 0; const std::string all(text.data(), (size_t)len); while (p < all.size()) { size_t e = all.find('\n', p); if (e == std::string::npos) e = all.size(); if (e > p) enc.record(out, all.substr(p, e - p)); p = e + 1; } }
+    double t_parse = 0, t_device = 0, t_format = 0;
+    const auto t_run0 = clk::now();
+    const bool serial = getenv("STITCH_ALIGN_SERIAL") != nullptr;      // (debugging) the three stages one after the other on this thread
+    if (serial) { to_align.cap = ~(size_t)0; to_write.cap = ~(size_t)0; }
+    auto reader_body = [&]() {
+        Work w; Rec r; long rec_no = 0;
+        if (worker && a.shard_offset > 0) { reads.seek(a.shard_offset); rec_no = a.shard_lo; }      // (no re-parsing of the blocks before this worker's)
+        auto t0 = clk::now();
+        while (reads.next(r)) {
+            const long k = rec_no++;
+            if (worker && (k < a.shard_lo || k >= a.shard_hi)) { if (k >= a.shard_hi) break; continue; }
+            w.recs.push_back(r);
+            if (w.recs.size() >= a.batch) { t_parse += secs(t0, clk::now()); to_align.push(std::move(w)); w = Work(); t0 = clk::now(); }
         }
-        n_reads += batch.size(); batch.clear();
-        if (!out.bam) fflush(stdout);
+        t_parse += secs(t0, clk::now());
+        if (!w.recs.empty()) to_align.push(std::move(w));
+        to_align.close();
     };
-    Rec r; long rec_no = 0;
-    if (worker && a.shard_offset > 0) { reads.seek(a.shard_offset); rec_no = a.shard_lo; }      // (no re-parsing of the blocks before this worker's)
-    while (reads.next(r)) {
-        const long k = rec_no++;
-        if (worker && (k < a.shard_lo || k >= a.shard_hi)) { if (k >= a.shard_hi) break; continue; }
-        batch.push_back(r); if (batch.size() >= a.batch) run_batch();
+    std::thread reader; if (serial) reader_body(); else reader = std::thread(reader_body);
+    std::vector<const char*> tn; std::vector<uint32_t> tl;
+    for (size_t k = 0; k < names.size(); ++k) { tn.push_back(names[k].c_str()); tl.push_back((uint32_t)seqs[k].size()); }
+    auto writer_body = [&]() {
+        Work w; std::vector<char> text(1 << 20);
+        while (to_write.pop(w)) {
+            const auto t0 = clk::now();
+            for (size_t k = 0; k < w.recs.size(); ++k) {
+                const Rec& r = w.recs[k]; const stitch_read_result& R = w.rr[k];
+                long len;
+                for (;;) {
+                    len = stitch_format_sam_chains(&a.o, tn.data(), tl.data(), (uint32_t)tn.size(), r.head.c_str(), (const uint8_t*)r.seq.data(),
+                                                   r.has_qual ? (const uint8_t*)r.qual.data() : nullptr, r.seq.size(), w.ch.data() + R.chains_begin, R.n_chains, w.ops.data(),
+                                                   R.has_prealign, R.prealign_score, text.data(), text.size());
+                    if (len < 0) die(stitch_last_error());
+                    if ((size_t)len < text.size()) break;
+                    text.resize((size_t)len + 1);
+                }
+                if (!out.bam) { out.put(text.data(), (size_t)len); if (len) out.put("\n", 1); }
+                else { size_t p = 0; const std::string all(text.data(), (size_t)len); while (p < all.size()) { size_t e = all.find('\n', p); if (e == std::string::npos) e = all.size(); if (e > p) enc.record(out, all.substr(p, e - p)); p = e + 1; } }
+            }
+            if (!out.bam) fflush(stdout);
+            t_format += secs(t0, clk::now());
+        }
+    };
+    std::thread writer; if (!serial) writer = std::thread(writer_body);
+    {
+        Work w;
+        while (to_align.pop(w)) {
+            const auto t0 = clk::now();
+            std::string cat; std::vector<uint64_t> offs(w.recs.size() + 1, 0);
+            for (size_t k = 0; k < w.recs.size(); ++k) { cat += w.recs[k].seq; offs[k + 1] = cat.size(); }
+            const stitch_read_result* rr; const stitch_chain* ch; const stitch_op* ops; uint64_t cells = 0;
+            if (stitch_align_batch(ctx, (const uint8_t*)cat.data(), offs.data(), (uint32_t)w.recs.size(), &rr, &ch, &ops, &cells) != STITCH_OK) die(stitch_last_error());
+            cells_total += cells; n_reads += w.recs.size();
+            // (the copy the writer formats from: the arrays themselves are the library's until the next call)
+            w.rr.assign(rr, rr + w.recs.size());
+            size_t n_ch = 0, n_ops = 0;
+            for (const stitch_read_result& R : w.rr) n_ch = std::max<size_t>(n_ch, (size_t)R.chains_begin + R.n_chains);
+            w.ch.assign(ch, ch + n_ch);
+            for (const stitch_chain& c2 : w.ch) n_ops = std::max<size_t>(n_ops, (size_t)c2.ops_begin + c2.ops_len);
+            w.ops.assign(ops, ops + n_ops);
+            t_device += secs(t0, clk::now());
+            to_write.push(std::move(w)); w = Work();
+        }
+        to_write.close();
     }
-    run_batch();
+    if (serial) writer_body(); else { reader.join(); writer.join(); }
+    const double t_all = secs(t_run0, clk::now());
     out.finish();
-    fprintf(stderr, "stitch-align: %llu reads, %.3f Gcells\n", (unsigned long long)n_reads, cells_total / 1e9);
+    fprintf(stderr, "stitch-align: %llu reads, %.3f Gcells in %.2f s = %.1f reads/s end to end (reader %.2f s, device calls %.2f s, formatter + writer %.2f s, side by side)\n",
+            (unsigned long long)n_reads, cells_total / 1e9, t_all, n_reads / std::max(t_all, 1e-9), t_parse, t_device, t_format);
     stitch_ctx_destroy(ctx); stitch_index_destroy(index);
     return 0;
 }

@@ -98,7 +98,7 @@ struct Knobs {
     size_t array_align = 0, job_align = 0;
     std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
-    int regs_waves = 0, regs_map = 0; bool trace = false, no_stream = false, no_join = false, no_wg_poll = false, prealign_general = false; int stream_blocks = 0, stream_teams = 0, stream_range = 0;      // (experiments) waves per workgroup of fill_regs.hip, order of its wave map; launch timeline on stderr
+    int regs_waves = 0, regs_map = 0; bool trace = false, no_stream = false, no_join = false, no_wg_poll = false, prealign_general = false; int stream_blocks = 0, stream_teams = 0, stream_range = 0; bool test_stream_stall = false;      // (experiments) waves per workgroup of fill_regs.hip, order of its wave map; launch timeline on stderr
     static Knobs from_env() {
         Knobs k;
         auto num = [](const char* name) -> unsigned long long { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : 0ull; };
@@ -123,6 +123,7 @@ struct Knobs {
         k.no_stream = getenv("STITCH_NO_STREAM") != nullptr;      // launch by launch even where persistent teams apply (A/B runs, tests)
         k.stream_blocks = (int)num("STITCH_STREAM_BLOCKS");       // (tests) cap on the arena blocks of a persistent-team run
         k.stream_range = (int)num("STITCH_STREAM_RANGE");         // (experiments) most jobs walked by one fix-up + walk launch
+        k.test_stream_stall = getenv("STITCH_TEST_STREAM_STALL") != nullptr;      // (tests) the first bounded wait beside resident teams counts as a stall: the run is called off
         k.stream_teams = (int)num("STITCH_STREAM_TEAMS");         // (tests) ... and on its teams, so that small batches queue up behind few teams
         if (const char* e = getenv("STITCH_REGS_MIN_ROWS")) k.regs_min_rows = atol(e);     // (tests: 0 sends every eligible read to fill_regs.hip)
         return k;
@@ -169,6 +170,9 @@ struct stitch_ctx {
     int regs32_wg_per_cu = 0;                    // ... of fill_regs32.hip (one: a wave takes a SIMD's whole register file)
     bool tm_fast = false;                        // last run_jobs used the Local-mode 16-bit kernel
     bool in_stream_fallback = false;             // run_jobs_streaming is on the stack (its fallback goes launch by launch)
+    uint32_t* stream_abort_word = nullptr;        // persistent teams running: the pinned word that calls the run off (set by bounded_sync when a launch beside them does not end)
+    bool stream_stalled = false;                 // ... and that it happened
+    bool warmed_up = false;                      // a classic launch of the register-resident fill with its walk and downloads has completed in this context
     size_t mem_limit = 0;                        // optional cap on arena bytes (STITCH_ARENA_BYTES), for tests
     // banded pre-alignment filter (prealign.h): host copies of the contig strands, their k-mer indexes, device scratch
     std::vector<uint8_t> h_xseq; std::vector<Strand> strands; KmerIndex kidx;
@@ -510,6 +514,27 @@ int pick_waves(const stitch_ctx& c, uint32_t nact, int maxw) {          // fewes
     return best_w;
 }
 
+// Waiting for the second stream while persistent teams are resident.  The fix-up / walk kernels and the runtime's copy kernels of that
+// stream need one of the few wave slots the teams leave free, and the dispatcher deals workgroups to the shader engines in a fixed
+// rotation: now and then (seen about once in a few thousand launches) a workgroup's turn falls on an engine the teams fill completely and
+// it waits there for as long as they stay.  They stay until the queue is empty — so a wait that lasts beyond a bound calls the run off
+// (the teams leave after the read they are on, the stuck launch then runs) and what is left goes launch by launch.
+static int bounded_sync(stitch_ctx& c, hipStream_t s) {
+    if (!c.stream_abort_word) { HIP_TRY(hipStreamSynchronize(s)); return STITCH_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return STITCH_OK;
+        if (e != hipErrorNotReady) return fail(STITCH_EDEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+        if ((std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 1.5 || c.knobs.test_stream_stall) && !c.stream_stalled) {
+            c.stream_stalled = true;
+            *(volatile uint32_t*)c.stream_abort_word = 1u;
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
 // Chains of the jobs [k0, k0 + nj) after their fix-up + walk: headers first, then the operation lists, both batched through a pinned
 // staging buffer (one synchronous pageable copy per chain costs ~0.15 ms each; --suboptimal yields hundreds of chains per read).
 // blocks[q] = the arena block of job k0 + q, d_views = the launch's job table (entry q = job k0 + q).  A chain whose operations did not
@@ -526,7 +551,7 @@ int download_chains(stitch_ctx& c, hipStream_t sB, std::vector<Job>& jobs, const
             size_t i = 0;
             while (i < pend.size()) {
                 if (pend[i].bytes > PIN_BYTES) {
-                    if (!allow_rewalk) { HIP_TRY(hipMemcpyAsync(pend[i].dst, pend[i].src, pend[i].bytes, hipMemcpyDeviceToHost, sB)); HIP_TRY(hipStreamSynchronize(sB)); }
+                    if (!allow_rewalk) { HIP_TRY(hipMemcpyAsync(pend[i].dst, pend[i].src, pend[i].bytes, hipMemcpyDeviceToHost, sB)); if (int e2 = bounded_sync(c, sB)) return e2; }
                     else HIP_TRY(hipMemcpy(pend[i].dst, pend[i].src, pend[i].bytes, hipMemcpyDeviceToHost));
                     ++i; continue;
                 }
@@ -535,7 +560,7 @@ int download_chains(stitch_ctx& c, hipStream_t sB, std::vector<Job>& jobs, const
                     HIP_TRY(hipMemcpyAsync(c.pin + used, pend[j].src, pend[j].bytes, hipMemcpyDeviceToHost, sB));
                     used += align_up(pend[j].bytes, 64); ++j;
                 }
-                HIP_TRY(hipStreamSynchronize(sB));
+                if (int e2 = bounded_sync(c, sB)) return e2;
                 used = 0;
                 for (size_t k = i; k < j; ++k) { memcpy(pend[k].dst, c.pin + used, pend[k].bytes); used += align_up(pend[k].bytes, 64); }
                 i = j;
@@ -789,6 +814,8 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
     HIP_TRY(hipMemcpyAsync(d_ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, sB));
     HIP_TRY(hipStreamSynchronize(sB));
     c.tm.h2d_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h2d0).count();
+    if (const char* e = getenv("STITCH_STREAM_SETTLE_MS")) { HIP_TRY(hipDeviceSynchronize()); std::this_thread::sleep_for(std::chrono::milliseconds(atoi(e))); }      // (experiment)
+    c.stream_abort_word = c.pin_q + 16; c.stream_stalled = false;
     hq[0] = (uint32_t)std::min(N, B);                  // the first B jobs find their blocks free
     std::atomic_thread_fence(std::memory_order_seq_cst);
     hipEvent_t* const ev = c.evp[0];
@@ -815,7 +842,7 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
         while (b < N && hq[64 + b] != 0u && b - fin < range_cap) ++b;
         if (b == fin) {
             if (hq[32] != 0u) { broken = true; break; }                            // a wave gave up waiting (partner not resident, lost mailbox)
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count() > 30.0 + 1e-3 * (double)lay[fin].n) { broken = true; break; }      // (no read takes that long)
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count() > 5.0 + 1e-3 * (double)lay[fin].n) { broken = true; break; }      // (no read takes that long: 10 us per column is the rule)
             std::this_thread::sleep_for(std::chrono::microseconds(40));
             continue;
         }
@@ -828,10 +855,10 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[3], sB));
         const double tr0 = kn.trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count() : 0.0;
-        if (kn.trace) HIP_TRY(hipStreamSynchronize(sB));
+        if (kn.trace) { if (int e2 = bounded_sync(c, sB)) return e2; }
         const double tr1 = kn.trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count() : 0.0;
         for (uint32_t q2 = 0; q2 < nj; ++q2) HIP_TRY(hipMemcpyAsync(c.pin + 4ull * q2, views[fin + q2].err, 4, hipMemcpyDeviceToHost, sB));
-        HIP_TRY(hipStreamSynchronize(sB));
+        if (int e2 = bounded_sync(c, sB)) return e2;
         const double tr2 = kn.trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count() : 0.0;
         { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); c.tm.walk_ms += ms; if (kn.trace) fprintf(stderr, "[trace] jobs %zu-%zu: walk submitted %.1f, done %.1f (kernel %.2f ms), error words %.1f\n", fin, b, tr0, tr1, ms, tr2); }
         for (uint32_t q2 = 0; q2 < nj; ++q2) {
@@ -845,13 +872,16 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
         const int rd = download_chains(c, sB, jobs, lay, fin, nj, blk, d_views + fin, false);
         if (rd == 1) { broken = true; break; }           // a chain wants the exact-size re-walk (device-synchronising): the classic path does it
         if (rd) { rc_fatal = rd; broken = true; break; }
+        if (c.stream_stalled) { fin = b; broken = true; if (kn.trace) fprintf(stderr, "[trace] a launch beside the teams did not end within its bound: the run is called off after job %zu\n", b); break; }
         if (kn.trace) fprintf(stderr, "[trace] jobs %zu-%zu walked and downloaded at %.1f ms\n", fin, b, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count());
         fin = b;
         std::atomic_thread_fence(std::memory_order_release);
         hq[0] = (uint32_t)std::min(N, fin + B);
         t_last = std::chrono::steady_clock::now();
     }
+    if (c.stream_stalled) broken = true;
     if (broken) { hq[16] = 1u; std::atomic_thread_fence(std::memory_order_seq_cst); }
+    c.stream_abort_word = nullptr;
     HIP_TRY(hipStreamSynchronize(sA));                  // (every team leaves once the queue is empty or called off; every wait in the kernel is bounded)
     { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); c.tm.fill_ms += ms; c.tm.fill_kernel_ms += ms; }
     c.tm.launches += 1; c.tm.jobs += (uint32_t)fin; c.tm.stream_runs += 1;
@@ -880,9 +910,32 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
 static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     if (jobs.empty()) return STITCH_OK;
     if (!c.in_stream_fallback) {
+        // A context's first jobs always go launch by launch.  Whatever the runtime sets up on first use — code objects, its copy kernels, pools
+        // that grow — must not happen for the first time beside resident teams: measured, the first call of a process as a persistent-team
+        // run stalls for the kernel's whole bounded waits (86 s against 0.8 s for the same call made second, gpurun_out/r4t, r4v), and one
+        // small classic call before it is enough.  So the first jobs of a context's first eligible call (a quarter of them, at most 40) run as one classic launch.
+        if (!c.warmed_up && !c.knobs.no_stream && jobs.size() >= 4) {
+            bool uniform = true;
+            for (const Job& jb : jobs) if (jb.act.size() != jobs[0].act.size() || regs_plan(c, jb) == 0) { uniform = false; break; }
+            if (uniform) {
+                const size_t H = std::min<size_t>(40, std::max<size_t>(1, jobs.size() / 4));
+                std::vector<Job> head; head.reserve(H);
+                for (size_t k = 0; k < H; ++k) head.push_back(std::move(jobs[k]));
+                c.in_stream_fallback = true;
+                int rc = run_jobs_in_order(c, head);
+                c.in_stream_fallback = false;
+                for (size_t k = 0; k < H; ++k) jobs[k] = std::move(head[k]);
+                if (rc) return rc;
+                std::vector<Job> rest; rest.reserve(jobs.size() - H);
+                for (size_t k = H; k < jobs.size(); ++k) rest.push_back(std::move(jobs[k]));
+                rc = run_jobs_in_order(c, rest);
+                for (size_t k = H; k < jobs.size(); ++k) jobs[k] = std::move(rest[k - H]);
+                return rc;
+            }
+        }
         bool handled = false;
         c.in_stream_fallback = true;                  // (the persistent-team run hands what it could not finish to this function)
-        const int rc = run_jobs_streaming(c, jobs, &handled);
+        const int rc = c.warmed_up ? run_jobs_streaming(c, jobs, &handled) : STITCH_OK;
         c.in_stream_fallback = false;
         if (rc || handled) return rc;
     }
@@ -1407,6 +1460,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         pend = slot; k0 = ring[slot].k1;
     }
     if (pend >= 0) { if (int e = finish(ring[pend])) return e; }
+    if (c.tm.fill_kind == 2u) c.warmed_up = true;
     return STITCH_OK;
 }
 

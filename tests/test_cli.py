@@ -19,6 +19,9 @@ def cli():
 
 
 def run(cli, *args, check=True):
+    # (BAM is the default output, as the reference's; the tests that read records as text ask for SAM)
+    if "-r" in args and "--output-format" not in args:
+        args = (*args, "--output-format", "sam")
     r = subprocess.run([cli, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     if check:
         assert r.returncode == 0, r.stderr.decode()
@@ -261,7 +264,7 @@ def test_index_broadcast_over_rccl(cli, tmp_path):
     fq = tmp_path / "r.fq"; fq.write_text("".join(f"@r{k}\n{r.decode()}\n+\n{'I' * len(r)}\n" for k, r in enumerate(synth.make_reads(db, 9, 150, 4))))
     strip = lambda ls: [l for l in ls if not l.startswith("@PG")]
     one = run(cli, "-f", str(fq), "-r", str(ref)).stdout.decode().splitlines()
-    r = subprocess.run([cli, "-f", str(fq), "-r", str(ref), "--devices", "0", "--index-via", "rccl"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    r = subprocess.run([cli, "-f", str(fq), "-r", str(ref), "--devices", "0", "--index-via", "rccl", "--output-format", "sam"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-1500:]
     assert b"over RCCL" in r.stderr
     assert strip(r.stdout.decode().splitlines()) == strip(one)

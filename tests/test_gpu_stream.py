@@ -33,7 +33,9 @@ def test_the_persistent_teams_are_what_runs(monkeypatch):
     al = _aligners(db)
     got = al.align(reads)
     tm = al.timing()
-    assert tm["fill_kind"] == 2 and tm["stream_runs"] == 1 and tm["launches"] == 1 and tm["fallbacks"] == 0, tm
+    # (a context's first jobs go as one classic launch — what the runtime sets up on first use must not happen beside resident teams —
+    # and the rest of the call through the queue)
+    assert tm["fill_kind"] == 2 and tm["stream_runs"] == 1 and tm["launches"] == 2 and tm["fallbacks"] == 0, tm
     monkeypatch.setenv("STITCH_NO_STREAM", "1")
     al2 = _aligners(db)
     want = al2.align(reads)
@@ -97,3 +99,15 @@ def test_a_chain_beyond_its_buffer_ends_the_run_and_the_classic_path_finishes(mo
     targets = [(f"c{k}", P.rand_seq(rng, 300)) for k in range(3)]
     reads = [P.chimera(rng, targets, 200, both=False) for _ in range(6)]
     P.run_pair(targets, reads, gap_open=0, gap_extend=-1, check_sam=False)
+
+
+def test_a_stalled_launch_beside_the_teams_calls_the_run_off(monkeypatch):
+    """a fix-up / walk launch (or a copy) beside resident teams that does not end within its bound: the host calls the run off, the teams
+    leave after the read they are on, and what is left goes launch by launch (test hook: the first wait counts as a stall)"""
+    monkeypatch.setenv("STITCH_TEST_STREAM_STALL", "1")
+    rng = random.Random(77)
+    targets = [(f"c{k}", P.rand_seq(rng, n)) for k, n in enumerate([800, 500, 900])]
+    reads = [P.chimera(rng, targets, rng.randint(80, 400), both=False) for _ in range(16)]
+    al = P.run_pair(targets, reads)
+    tm = al.timing()
+    assert tm["stream_runs"] == 1 and tm["fallbacks"] == 1, tm

@@ -1,0 +1,15 @@
+#!/bin/bash
+O=gpurun_out/r4u; mkdir -p $O
+python - <<PY
+import sys; sys.path.insert(0,'.')
+from stitch_amd import synth
+db = synth.make_db(50, 5000, 1001)
+reads = synth.make_reads(db, 1280, 10000, 44)
+open('/tmp/ref.fa','w').write(''.join(f'>{n}\n{s.decode()}\n' for n,s in db))
+open('/tmp/r.fq','w').write(''.join(f'@read_{k:07d}\n{r.decode()}\n+\n{"I"*len(r)}\n' for k,r in enumerate(reads)))
+PY
+run() { tag=$1; shift; ( export "$@"; timeout -k 10 200 stitch_amd/bin/stitch-align -f /tmp/r.fq -r /tmp/ref.fa --batch 640 > /dev/null 2> $O/$tag.err ); echo "$tag: $(grep 'stitch-align:' $O/$tag.err | cut -c1-200)" | tee -a $O/log.txt; }
+run first_process STITCH_X=1
+sleep 20
+run after_20s_pause STITCH_X=1
+run back_to_back STITCH_X=1
