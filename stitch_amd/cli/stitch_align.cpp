@@ -513,7 +513,7 @@ int main(int argc, char** argv) {
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     uint64_t n_reads = 0, cells_total = 0;
-    double t_parse = 0, t_device = 0, t_format = 0;
+    double t_parse = 0, t_device = 0, t_format = 0, t_device_first = 0; uint64_t n_first = 0;      // (the first call also sizes and allocates the device arena: seconds)
     const auto t_run0 = clk::now();
     const bool serial = getenv("STITCH_ALIGN_SERIAL") != nullptr;      // (debugging) the three stages one after the other on this thread
     if (serial) { to_align.cap = ~(size_t)0; to_write.cap = ~(size_t)0; }
@@ -573,7 +573,9 @@ int main(int argc, char** argv) {
             w.ch.assign(ch, ch + n_ch);
             for (const stitch_chain& c2 : w.ch) n_ops = std::max<size_t>(n_ops, (size_t)c2.ops_begin + c2.ops_len);
             w.ops.assign(ops, ops + n_ops);
-            t_device += secs(t0, clk::now());
+            const double dt_call = secs(t0, clk::now());
+            if (t_device == 0) { t_device_first = dt_call; n_first = w.recs.size(); }
+            t_device += dt_call;
             to_write.push(std::move(w)); w = Work();
         }
         to_write.close();
@@ -581,8 +583,9 @@ int main(int argc, char** argv) {
     if (serial) writer_body(); else { reader.join(); writer.join(); }
     const double t_all = secs(t_run0, clk::now());
     out.finish();
-    fprintf(stderr, "stitch-align: %llu reads, %.3f Gcells in %.2f s = %.1f reads/s end to end (reader %.2f s, device calls %.2f s, formatter + writer %.2f s, side by side)\n",
-            (unsigned long long)n_reads, cells_total / 1e9, t_all, n_reads / std::max(t_all, 1e-9), t_parse, t_device, t_format);
+    fprintf(stderr, "stitch-align: %llu reads, %.3f Gcells in %.2f s = %.1f reads/s end to end (reader %.2f s, device calls %.2f s, formatter + writer %.2f s, side by side; first call %.2f s for %llu reads, the others %.1f reads/s)\n",
+            (unsigned long long)n_reads, cells_total / 1e9, t_all, n_reads / std::max(t_all, 1e-9), t_parse, t_device, t_format, t_device_first, (unsigned long long)n_first,
+            n_reads > n_first ? (n_reads - n_first) / std::max(t_device - t_device_first, 1e-9) : 0.0);
     stitch_ctx_destroy(ctx); stitch_index_destroy(index);
     return 0;
 }

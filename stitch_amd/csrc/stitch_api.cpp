@@ -120,7 +120,12 @@ struct Knobs {
         k.no_wg_poll = getenv("STITCH_NO_WG_POLL") != nullptr;    // every wave polls its team's granules itself even where a workgroup's waves are one team's (A/B runs)
         k.prealign_general = getenv("STITCH_PREALIGN_GENERAL") != nullptr;      // (tests) the filter's general path (every mode, 32-bit band ranges) also where the fast Local path applies
         k.no_join = getenv("STITCH_NO_JOIN") != nullptr;          // traceback_all: every chain walked to its start (A/B runs, tests), none joined to the reference chain
-        k.no_stream = getenv("STITCH_NO_STREAM") != nullptr;      // launch by launch even where persistent teams apply (A/B runs, tests)
+        k.no_stream = getenv("STITCH_NO_STREAM") != nullptr;
+        // Under rocprofv3 (kernel trace or counters) a launch beside resident teams is not reported complete until the teams' own dispatch
+        // is: the tool handles completions in submission order (measured: the first walk of every persistent run "stalls", the run is called
+        // off after its bound and continues launch by launch, gpurun_out/collect_r04_a/trace).  A profiled process therefore goes launch by
+        // launch from the start, and says so (stitch_timing.stream_runs stays 0); bench.py prints which path ran.
+        { const char* pre = getenv("LD_PRELOAD"); if (getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || (pre && strstr(pre, "rocprofiler"))) k.no_stream = true; }      // launch by launch even where persistent teams apply (A/B runs, tests)
         k.stream_blocks = (int)num("STITCH_STREAM_BLOCKS");       // (tests) cap on the arena blocks of a persistent-team run
         k.stream_range = (int)num("STITCH_STREAM_RANGE");         // (experiments) most jobs walked by one fix-up + walk launch
         k.test_stream_stall = getenv("STITCH_TEST_STREAM_STALL") != nullptr;      // (tests) the first bounded wait beside resident teams counts as a stall: the run is called off
@@ -377,7 +382,7 @@ int stitch_ctx_create(int device_ordinal, const stitch_index* idx, const stitch_
     }
     if (const char* lim = getenv("STITCH_ARENA_BYTES")) c->mem_limit = (size_t)strtoull(lim, nullptr, 10);
     c->knobs = Knobs::from_env();
-    c->regs_waves = (c->knobs.regs_waves == 4 || c->knobs.regs_waves == 8) ? (uint32_t)c->knobs.regs_waves : REGS_WAVES_DEFAULT;
+    c->regs_waves = (c->knobs.regs_waves == 2 || c->knobs.regs_waves == 4 || c->knobs.regs_waves == 8) ? (uint32_t)c->knobs.regs_waves : REGS_WAVES_DEFAULT;
     c->regs_wg_per_cu = fill_regs_workgroups_per_cu(c->regs_waves);
     c->regs32_wg_per_cu = fill_regs32_workgroups_per_cu();
     *out = c.release();
@@ -1762,6 +1767,8 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
     HIP_TRY(hipEventRecord(c.ev2[0], PS0));
     HIP_TRY(hipStreamWaitEvent(PS1, c.ev2[0], 0));
     std::vector<Staged> staged(chunks.size());
+    uint32_t cnt_seen[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 256, PS2));                     // the band kernel's class counts: cleared once per call
     auto device_stage = [&](size_t i) -> int {                       // asynchronous: everything of chunk i on the second stream, then its event
         Staged& S = staged[i];
         const size_t np = (S.k1 - S.k0) * C, g0 = S.k0 * C;
@@ -1788,17 +1795,21 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
             // only the score kernels that have pairs (an empty one still costs its launch and 5000 workgroups that come and go: 3 ms
             // of the 13 a chunk took), each of which skips the others' pairs
             const uint32_t nb = (uint32_t)S.banded_ids.size();
+            // (the counts are CUMULATIVE over the call's chunks, cleared once per call: a 16-byte clear per chunk is a kernel of its own that
+            // queues for a wave slot behind the score kernels' thousands of workgroups — 10-35 ms of the pipeline's latency each in
+            // profiles/r04_a_kernel_stats_cfg3.csv's trace, `__amd_rocclr_fillBufferAligned` 6.5 % of the GPU time)
             uint32_t* const cnt_d = d_cnt + 4 * (i & 1); uint32_t* const cnt_h = c.pin_cnt + 4 * (i & 1);
-            HIP_TRY(hipMemsetAsync(cnt_d, 0, 16, up));
             launch_band_draw(d_pairs, d_banded, nb, max_n, d_elems, (uint32_t)c.opts.band_width, banded_ring_rows(), win_scoring, d_bands, d_cls, cnt_d, up);
             HIP_TRY(hipMemcpyAsync(cnt_h, cnt_d, 16, hipMemcpyDeviceToHost, up));
             HIP_TRY(hipEventRecord(c.evu[i & 1], up));
             HIP_TRY(hipEventSynchronize(c.evu[i & 1]));
             HIP_TRY(hipStreamWaitEvent(PS1, c.evu[i & 1], 0));
-            if (cnt_h[BAND_CLASS_WINDOW]) launch_banded_scores_window(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_scores, d_cls, PS1);
-            if (cnt_h[BAND_CLASS_RING] && !launch_banded_scores_lds(d_pairs, d_banded, nb, S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, d_cls, PS1))
+            uint32_t cnt_now[4];
+            for (int k4 = 0; k4 < 4; ++k4) { cnt_now[k4] = cnt_h[k4] - cnt_seen[i & 1][k4]; cnt_seen[i & 1][k4] = cnt_h[k4]; }
+            if (cnt_now[BAND_CLASS_WINDOW]) launch_banded_scores_window(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_scores, d_cls, PS1);
+            if (cnt_now[BAND_CLASS_RING] && !launch_banded_scores_lds(d_pairs, d_banded, nb, S.banded_max_m, sc, d_reads, c.d_xseq, d_bands, d_scores, d_cls, PS1))
                 launch_banded_scores(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, d_cls, BAND_CLASS_RING, PS1);
-            if (cnt_h[BAND_CLASS_TALL]) launch_banded_scores(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, d_cls, BAND_CLASS_TALL, PS1);
+            if (cnt_now[BAND_CLASS_TALL]) launch_banded_scores(d_pairs, d_banded, nb, sc, d_reads, c.d_xseq, d_bands, d_state, d_scores, d_cls, BAND_CLASS_TALL, PS1);
         } else {
             HIP_TRY(hipEventRecord(c.evu[i & 1], up));
             HIP_TRY(hipStreamWaitEvent(PS1, c.evu[i & 1], 0));

@@ -44,10 +44,12 @@ def main():
             if r.returncode != 0:
                 raise SystemExit(r.stderr.decode()[-2000:])
             line = [l for l in r.stderr.decode().splitlines() if l.startswith("stitch-align:") and "reads/s" in l][-1]
-            m = re.search(r"(\d+) reads, ([\d.]+) Gcells in ([\d.]+) s = ([\d.]+) reads/s end to end \(reader ([\d.]+) s, device calls ([\d.]+) s, formatter \+ writer ([\d.]+) s", line)
+            m = re.search(r"(\d+) reads, ([\d.]+) Gcells in ([\d.]+) s = ([\d.]+) reads/s end to end \(reader ([\d.]+) s, device calls ([\d.]+) s, formatter \+ writer ([\d.]+) s, side by side; first call ([\d.]+) s for (\d+) reads, the others ([\d.]+) reads/s", line)
             res[fmt] = {"process_seconds": dt, "process_reads_per_sec": args.reads / dt, "output_bytes": len(r.stdout),
                         "loop_seconds": float(m.group(3)), "loop_reads_per_sec": float(m.group(4)), "reader_s": float(m.group(5)),
-                        "device_calls_s": float(m.group(6)), "formatter_writer_s": float(m.group(7)), "device_calls_reads_per_sec": args.reads / float(m.group(6))}
+                        "device_calls_s": float(m.group(6)), "formatter_writer_s": float(m.group(7)), "device_calls_reads_per_sec": args.reads / float(m.group(6)),
+                        "first_call_s": float(m.group(8)), "device_calls_after_the_first_reads_per_sec": float(m.group(10)),
+                        "loop_after_first_call_reads_per_sec": (args.reads - int(m.group(9))) / max(1e-9, float(m.group(3)) - float(m.group(8)))}
         out = {"what": "stitch-align (stitch_amd/cli) on files, cfg2 shape: 10 kb reads vs 50 x 5 kb, local, single strand", "reads": args.reads, "batch": args.batch,
                "note": "process = fork to exit incl. FASTA load, index, context and the first call's arena allocation (~5 s); loop = first read parsed to last record written; "
                        "device calls = time inside stitch_align_batch (what bench.py times), with reader and writer threads running beside it", **res}
