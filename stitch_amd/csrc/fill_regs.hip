@@ -853,11 +853,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     // ---- column n's arrays for the fix-up kernel (single_contig_aligner.rs:453-555): the final words, and the insertion chain at
     // every row — recomputed here from the final words (an opener taken from a merged cell gives the same chain, see above)
     {
-        uint32_t gl_x = gl; int32_t pos_x = pos1_0; asm volatile("" : "+v"(gl_x), "+v"(pos_x));
-        const uint32_t rg4_x = 4u * (roff + (uint32_t)pos_x - 1u + rsh);       // 4 x (linear row index of the row register 0 holds, or would hold)
-        const bool mine = lane == mlane;
+        // (the lane's geometry afresh from an untraceable lane number, as in the unpack loop below: nothing of it carried through the column loop)
+        uint32_t lane_o = threadIdx.x & 63u; asm volatile("" : "+v"(lane_o));
+        const uint32_t gl_o = gq + (lane_o < grem ? 1u : 0u), rsh_o = (grem > 0 && lane_o >= grem) ? 4u : 0u;
+        const bool has0_o = gl_o > 0 && rsh_o == 0u;
+        uint32_t gl_x = gl_o; int32_t pos_x = (int32_t)(4u * (lane_o * gq + (lane_o < grem ? lane_o : grem)) + 4u * gl_o);
+        const uint32_t rg4_x = 4u * (roff + (uint32_t)pos_x - 1u + rsh_o);       // 4 x (linear row index of the row register 0 holds, or would hold)
+        const bool mine = (int)lane_o == mlane;
         int32_t L = CHAIN_NONE; bool lext = false;
-#define GUARD(g) ((g) == 0 ? has0 : (uint32_t)(g) < gtop)
+#define GUARD(g) ((g) == 0 ? has0_o : (uint32_t)(g) < gtop)
 #define LASTA(g) if (GUARD(g)) { _Pragma("unroll") for (int k = 3; k >= 0; --k) { \
             const int32_t ext = L + GE1, open = (int32_t)S[4 * (g) + k] + GO1; lext = word_score(ext) >= word_score(open); L = lext ? ext : open; } }
         REP20(LASTA)
@@ -880,12 +884,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     if (lane == 0) { unsigned long long* const pf = (unsigned long long*)((uint8_t*)V.err + 16); for (int k = 0; k < 8; ++k) atomicAdd(pf + k, (unsigned long long)pf_sum[k]); atomicAdd(pf + 8, 1ull); atomicAdd(pf + 9, (unsigned long long)pf_cnt[0]); atomicAdd(pf + 10, (unsigned long long)pf_cnt[1]); for (int k = 0; k < 6; ++k) atomicAdd(pf + 11 + k, (unsigned long long)pf_cls[k]); }
 #endif
     // ---- unpack the y-suffix records of this wave's rows into the arrays the fix-up kernel reads (its own stores: no barrier) -------
+    // (the lane's geometry worked out afresh from a lane number the compiler cannot trace back: what it would otherwise carry through the
+    // column loop for this epilogue — addresses, row counts — it had to spill to scratch memory, which a persistent launch must not use)
+    {
+        uint32_t lane_o = threadIdx.x & 63u; asm volatile("" : "+v"(lane_o));
+        const uint32_t gl_o = gq + (lane_o < grem ? 1u : 0u), nrows_o = 4u * gl_o;
+        const uint32_t rowbase_o = 4u * (lane_o * gq + (lane_o < grem ? lane_o : grem)), rsh_o = (grem > 0 && lane_o >= grem) ? 4u : 0u;
+        const gptr<u32x2> yrec_o = (gptr<u32x2>)as_global(V.D);
 #pragma unroll 1
-    for (uint32_t i = 0; i < nrows; ++i) {
-        const uint32_t row = rowbase + (nrows - 1 - i);
-        if (row < m) {
-            const u32x2 rec = yrec[roff + (i + rsh) * 64u + (uint32_t)lane];
-            V.Sn[roff + row] = word_score((int32_t)rec.x); V.SnLen[roff + row] = word_len((int32_t)rec.x); V.Ly[roff + row] = rec.y;
+        for (uint32_t i = 0; i < nrows_o; ++i) {
+            const uint32_t row = rowbase_o + (nrows_o - 1 - i);
+            if (row < m) {
+                const u32x2 rec = yrec_o[roff + (i + rsh_o) * 64u + lane_o];
+                V.Sn[roff + row] = word_score((int32_t)rec.x); V.SnLen[roff + row] = word_len((int32_t)rec.x); V.Ly[roff + row] = rec.y;
+            }
         }
     }
     if (!streaming) return;
