@@ -38,7 +38,10 @@ __global__ __launch_bounds__(64) void band_draw_kernel(const BandPair* __restric
     uint32_t* lo = band_lds; uint32_t* hi = band_lds + (P.n + 1);
     const bool whole = P.n_elem == 0;                                 // no backbone: the band is the full matrix
     for (uint32_t c = lane; c <= P.n; c += 64) { lo[c] = whole ? 0u : (uint32_t)(m + 1); hi[c] = whole ? (uint32_t)(m + 1) : 0u; }
-    for (uint32_t e = 0; e < P.n_elem; ++e) {
+    // (a column one lane widened for one piece is another lane's column in the next piece: the workgroup is one wave, the barrier
+    // costs nothing, and the order no longer rests on how one wave's LDS operations happen to retire)
+    __syncthreads();
+    for (uint32_t e = 0; e < P.n_elem; ++e, __syncthreads()) {
         const BandElem E = elems[P.elem_off + e];
         if (E.d < 0) {
             const long r = E.a, c = E.b, len = E.c;

@@ -94,6 +94,7 @@ struct Job {                                     // one full jump DP
 // Diagnostic / experiment knobs, read from the environment ONCE when a context is created (never per launch).
 struct Knobs {
     bool fail_first_attempt = false;             // test hook: treat the first attempt of every cooperative launch as timed out
+    bool fail_keeps_pipeline = false;            // test hook ("pipelined"): ... and keep two fills in flight, so that a repeat runs beside the other window's fill
     bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false, no_regs32 = false, force_regs32 = false, no_pipeline = false, no_fill_overlap = false, prealign_v1 = false, host_bands = false;
     size_t array_align = 0, job_align = 0;
     std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
@@ -105,6 +106,7 @@ struct Knobs {
         k.debug = getenv("STITCH_DEBUG") != nullptr; k.force_generic = getenv("STITCH_FORCE_GENERIC") != nullptr;
         k.profile_dump = getenv("STITCH_PROFILE_DUMP") != nullptr; k.banded_global = getenv("STITCH_BANDED_GLOBAL") != nullptr;
         k.fail_first_attempt = getenv("STITCH_TEST_FAIL_FIRST_ATTEMPT") != nullptr;
+        { const char* e = getenv("STITCH_TEST_FAIL_FIRST_ATTEMPT"); k.fail_keeps_pipeline = e && !strcmp(e, "pipelined"); }
         k.fill_only = getenv("STITCH_EXP_FILL_ONLY") != nullptr;      // experiment builds whose results are garbage: time the fill, skip the walk
         k.no_regs = getenv("STITCH_NO_REGS") != nullptr;             // keep the state-streaming kernel even where the register-resident one applies
         k.no_fill_overlap = getenv("STITCH_NO_FILL_OVERLAP") != nullptr;      // two windows, but a fill starts only when the one before it has ended
@@ -1024,7 +1026,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
     if (c.knobs.debug) fprintf(stderr, "[stitch] job blocks at multiples of %zu bytes, window %zu bytes\n", block_align, want);
     // Two windows where more than one launch is expected and both fit: the fill of launch k + 1 then runs beside fix-up, walk,
     // downloads and host parsing of launch k (6 ms of 139 per launch at cfg2, more with --suboptimal's hundreds of chains).
-    const bool quiet = !c.knobs.debug && !c.knobs.profile_dump && !c.knobs.fill_only && c.knobs.dump_dir.empty() && !c.knobs.no_pipeline && !c.knobs.fail_first_attempt;
+    const bool quiet = !c.knobs.debug && !c.knobs.profile_dump && !c.knobs.fill_only && c.knobs.dump_dir.empty() && !c.knobs.no_pipeline && (!c.knobs.fail_first_attempt || c.knobs.fail_keeps_pipeline);
     const size_t win_align = std::max<size_t>(block_align, 256);
     const bool want_two = quiet && jobs.size() > win_jobs && 2 * align_up(want + (1 << 20), win_align) + win_align <= budget;
     // Where two full windows do not fit (cfg5: ten 20 kb reads against 200 contigs are 200 GB of traceback) but half the memory still
@@ -1641,7 +1643,9 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         while (k1 < NJ && k1 - k0 < PRE_CHUNK) {
             const size_t m = jobs[k1].y.size();
             size_t need = 0;
-            for (uint32_t a = 0; a < C; ++a) need += al256(4ull * (c.al[a].m + 1)) + al256(12ull * (m + 1)) + 16 + 64 * sizeof(BandElem);
+            // (a band's pieces: a diagonal and a gap per run of the backbone, runs at least k apart unless seeds overlap — a noisy multi-kb read
+            // on its true target has hundreds; what a chunk really needs is checked against its region when its pieces are known)
+            for (uint32_t a = 0; a < C; ++a) need += al256(4ull * (c.al[a].m + 1)) + al256(12ull * (m + 1)) + 16 + (2 * (std::min<size_t>(m, c.al[a].m) / (size_t)std::max(1, (int)c.opts.kmer_size)) + 4) * sizeof(BandElem);
             if (bytes + need + 4096 > region_bytes) break;
             bytes += need; ++k1;
         }
@@ -1780,7 +1784,7 @@ int run_prealign(stitch_ctx& c, std::vector<Job>& jobs, std::vector<uint8_t>& ha
         uint32_t* d_win = (uint32_t*)p; p += al256(S.win_ids.size() * 4);
         BandElem* d_elems = (BandElem*)p; p += al256(S.elems.size() * sizeof(BandElem));
         int32_t* d_state = (int32_t*)p; p += al256(S.state_elems * 4);
-        if (p > p_end) return fail(STITCH_EINTERNAL, "pre-alignment scratch overflow");
+        if (p > p_end) return fail(STITCH_ENOMEM, "pre_align: a chunk's bands have more pieces than its share of the pre-alignment scratch holds (STITCH_PREALIGN_BYTES)");
         // the uploads (128 MB of band ranges per 64 reads at cfg3) go on a stream of their own, beside the kernels of the chunk before
         hipStream_t up = PS2;
         if (!dev_bands) HIP_TRY(hipMemcpyAsync(d_bands, S.bands, S.band_elems * 2, hipMemcpyHostToDevice, up));
@@ -2112,6 +2116,8 @@ int stitch_prealign_band(const uint8_t* read, uint32_t read_len, const uint8_t* 
                          int32_t match, int32_t gap_open, int32_t gap_extend, uint16_t* lo, uint16_t* hi) {
     if (!read || !target || !lo || !hi) return fail(STITCH_EINVAL, "null argument");
     if (read_len > 65534) return fail(STITCH_EINVAL, "pre_align: reads longer than 65534 bases are not supported");
+    // (the backbone's pruned search is exact only for a gap penalty that grows with the gap; the context constructor rejects the same)
+    if (gap_open > 0 || gap_extend > 0) return fail(STITCH_EINVAL, "gap_open and gap_extend can't be positive");
     std::vector<Strand> st{Strand{0, target_len}};
     const KmerIndex ix = build_kmer_index(target, st, k);
     std::vector<std::vector<Seed>> seeds; std::vector<uint16_t> l, h;
@@ -2125,6 +2131,8 @@ int stitch_prealign_band_device(int device, const uint8_t* read, uint32_t read_l
                                 int32_t match, int32_t gap_open, int32_t gap_extend, uint16_t* lo, uint16_t* hi, uint32_t* kernel_class) {
     if (!read || !target || !lo || !hi) return fail(STITCH_EINVAL, "null argument");
     if (read_len > 65534) return fail(STITCH_EINVAL, "pre_align: reads longer than 65534 bases are not supported");
+    // (the backbone's pruned search is exact only for a gap penalty that grows with the gap; the context constructor rejects the same)
+    if (gap_open > 0 || gap_extend > 0) return fail(STITCH_EINVAL, "gap_open and gap_extend can't be positive");
     if (target_len + 1 > band_device_max_cols()) return fail(STITCH_EINVAL, "the device draws bands of up to 8191 columns");
     std::vector<Strand> st{Strand{0, target_len}};
     const KmerIndex ix = build_kmer_index(target, st, k);

@@ -445,7 +445,9 @@ struct WaveWalk {
     __device__ static uint32_t layer_word(uint32_t layer, bool yfirst) { return layer | (yfirst ? 0x100u : 0u); }
     __device__ bool enter_column(const JobView& V, uint32_t cur, uint32_t i, uint32_t j, uint32_t layer, uint32_t nops, uint32_t nonspecial, bool yfirst) const {
         if (role == 1) { if (lane == 0) { VisitRec r; r.contig = (uint16_t)cur; r.row = (uint16_t)i; r.layer = layer_word(layer, yfirst); r.nops = nops; r.nonspecial = nonspecial; V.visit[j + 1] = r; } return false; }
-        if (role != 2 || yfirst) return false;
+        // (never in column 0: a walk gets there through its prefix clips, which have set ITS start coordinates already — two chains that
+        // start in the same contig at different cells both arrive at (contig, row 0, column 0, start), and the one is not the other's prefix)
+        if (role != 2 || yfirst || j == 0) return false;
         const VisitRec r = V.visit[j + 1];
         if (r.contig == (uint16_t)cur && r.row == (uint16_t)i && r.layer == layer_word(layer, false)) { met = true; met_nops = r.nops; met_nonspecial = r.nonspecial; return true; }
         return false;

@@ -320,3 +320,15 @@ def test_partner_timeout_on_a_read_beyond_one_slot_table_falls_back_to_the_gener
     tm = al.timing()
     assert tm["fill_kind"] == 0 and tm["fallbacks"] >= 1 and tm["wg_per_read"] == 1, tm
 
+
+
+def test_a_chain_that_starts_elsewhere_in_the_reference_chains_contig(monkeypatch):
+    """--suboptimal, joined walks (walk_core.h VisitRec): a secondary chain that starts in the contig the reference chain starts in, at
+    another cell, arrives at (contig, row 0, column 0) in the reference walk's state once its own prefix clips are done — it must keep its
+    own start coordinates (found by tests/gpu_fuzz.py FUZZ_STREAM=1, seed 7087, read 11: circular, both strands, targets of 34, 1453, 5
+    and 29 bases)"""
+    monkeypatch.setenv("FUZZ_STREAM", "1")
+    from tests import gpu_fuzz as G
+    targets, reads, opts, _, _, lens = G.draw(7087)
+    assert lens == [34, 1453, 5, 29] and len(reads[11]) == 124 and opts["suboptimal"]
+    run_pair(targets, [reads[11], reads[3], reads[11]], **opts)

@@ -121,3 +121,17 @@ def test_partner_timeout_falls_back_to_one_workgroup_per_read(monkeypatch):
     al = P.run_pair(targets, reads, double_strand=True)
     tm = al.timing()
     assert tm["fallbacks"] >= 1 and tm["fill_kind"] == 1 and tm["wg_per_read"] == 1
+
+
+def test_a_repeated_launch_beside_the_other_windows_fill(monkeypatch):
+    """two fills in flight (two arena windows), more than two launches, and the first attempt of every launch counts as timed out: each
+    repeat (one workgroup per read) starts while the other window's fill is running, and every read still equals the oracle"""
+    monkeypatch.setenv("STITCH_TEST_FAIL_FIRST_ATTEMPT", "pipelined")
+    monkeypatch.setenv("STITCH_REGS_MIN_ROWS", "0")
+    db = synth.make_db(4, 2000, 14)
+    targets = [(n, s.decode()) for n, s in db]
+    reads = [r.decode() for r in synth.make_reads(db, 12, 1500, 16)]
+    monkeypatch.setenv("STITCH_ARENA_BYTES", str(64 << 20))      # (a read's traceback is 12 MB: two or three reads per window)
+    al = P.run_pair(targets, reads)
+    tm = al.timing()
+    assert tm["launches"] > 2 and tm["fallbacks"] >= 2, tm

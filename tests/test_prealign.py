@@ -112,6 +112,20 @@ def _bands(x, y, k, w, match=1, go=-6, ge=-2):
     return (full_p, lo.astype(np.uint32), hi.astype(np.uint32)), (full_o, olo, ohi)
 
 
+def test_the_band_entry_point_rejects_a_positive_gap_score():
+    """the backbone's pruned search assumes a penalty that grows with the gap (the context constructor rejects positive gap scores too)"""
+    import numpy as np
+    from stitch_amd import api
+    x = "ACGTACGTACGTTTGACCA"; y = "ACGTACGTACGTTTGACCAGGT"
+    xb = (C.c_uint8 * len(x)).from_buffer_copy(x.encode()); yb = (C.c_uint8 * len(y)).from_buffer_copy(y.encode())
+    lo = np.zeros(len(y) + 1, dtype=np.uint16); hi = np.zeros(len(y) + 1, dtype=np.uint16)
+    P16 = C.POINTER(C.c_uint16)
+    for go, ge in [(1, -2), (-6, 1)]:
+        rc = api.lib().stitch_prealign_band(xb, len(x), yb, len(y), 5, 3, 1, go, ge, lo.ctypes.data_as(P16), hi.ctypes.data_as(P16))
+        assert rc == -1 and b"positive" in api.lib().stitch_last_error()
+    assert api.lib().stitch_prealign_band(xb, len(x), yb, len(y), 5, 3, 1, 0, 0, lo.ctypes.data_as(P16), hi.ctypes.data_as(P16)) >= 0
+
+
 @pytest.mark.parametrize("seed", range(240))
 def test_product_band_equals_oracle_band(seed):
     """the library's host code (sorted k-mer index, analytic diagonal rasterisation) and the oracle's (maps, point by point)
