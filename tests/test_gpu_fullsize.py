@@ -109,3 +109,38 @@ def test_cfg2_reads_of_the_launch_equal_the_oracle_at_full_size(launch):
         assert [c.key() for c in got] == want_keys, f"read {k} differs from the oracle at n = {N}"
         assert al.format_sam(k, f"read_{k:07d}", reads[k], b"I" * N) == want_sam, f"SAM text of read {k}"
     assert len(results) >= 2
+
+
+def test_cfg2_size_reads_in_the_other_clipping_modes_equal_the_oracle():
+    """One 10 kb read per non-Local mode against the 50 x 5 kb contigs, through the 32-bit register-resident kernel
+    (fill_regs32.hip: scores of these modes leave the 16-bit range), chains, operation lists and SAM text compared with the oracle at
+    full size (aligners/constants.rs:96-136 for the modes' clip penalties, single_contig_aligner.rs:453-470 for the end-of-read jump)."""
+    modes = ["global", "query-local", "target-local"]
+    avail = mem_available()
+    workers = int(min(len(modes), (avail * 0.8) // (ORACLE_BYTES_PER_READ + (2 << 30))))
+    if workers < 1:
+        pytest.skip(f"the oracle needs {ORACLE_BYTES_PER_READ / 2**30:.0f} GiB per read, {avail / 2**30:.0f} GiB available")
+    db = synth.make_db(CONTIGS, M, 1001)
+    reads = synth.make_reads(db, 8, N, 44)
+    chimeric = [r for r in reads if r != reads[0]][:len(modes)]
+    targets = [(n, s.decode()) for n, s in db]
+    got = {}
+    for mode, read in zip(modes, chimeric):
+        al = stitch_amd.Builder(mode=mode).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in db])
+        res = al.align([read])
+        tm = al.timing()
+        assert tm["fill_kind"] == 3 and al.cells_filled == N * CONTIGS * M, (mode, tm)
+        got[mode] = ([c.key() for c in res[0][0]], al.format_sam(0, "read_0000000", read, b"I" * N))
+        del al
+
+    def oracle_read(item):
+        mode, read = item
+        o = orc.Aligners(targets, mode=mode)
+        want = o.align(read)
+        return mode, [c.key() for c in want], o.format_sam("read_0000000", read.decode(), "I" * N)
+
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        results = list(ex.map(oracle_read, zip(modes, chimeric)))
+    for mode, want_keys, want_sam in results:
+        assert got[mode][0] == want_keys, f"mode {mode}: chains differ from the oracle at n = {N}"
+        assert got[mode][1] == want_sam, f"mode {mode}: SAM text"
