@@ -241,7 +241,9 @@ __device__ __forceinline__ void group_records(Recs& R, const uint32_t g4, const 
 }  // namespace
 
 // NQ = granule registers per lane: 1 for up to 64 active contigs, 4 for up to 256
-template <int NQ, bool CIRC>
+// YB: every job of the launch keeps per-contig y-suffix records (--suboptimal, the re-alignments of --circular): a cell whose word is the
+// column's common word W = jump word + match is recorded as bit 7 of its traceback byte instead of an 8-byte record (see P2TAIL)
+template <int NQ, bool CIRC, bool YB>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS_WAVES_PER_EU, STITCH_REGS_WAVES_PER_EU))) void fill_regs_kernel(const JobView* __restrict__ jobs, FillShared sh, const uint2* __restrict__ wave_map, uint32_t n_waves, const StreamCtl* __restrict__ qp) {
     // The launch's waves are dealt to the reads' contigs DENSELY: wave w of the grid is entry w of `wave_map` = {read of the launch,
     // active contig of that read}.  A team (the waves of one read) needs nothing of a workgroup - no barrier, no shared LDS, the
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
                 if (row < m) { \
                     const uint32_t tr = cd.troff + row; \
                     S[4 * (g) + k] = (uint32_t)word_make(sh.S0[tr], sh.Slen0[tr]); \
-                    u32x2 rec; rec.x = (uint32_t)word_make(sh.Sn0[tr], sh.Slen0[tr]); rec.y = sh.SnSet0[tr] ? n : 0u; \
+                    u32x2 rec; rec.x = (uint32_t)word_make(sh.Sn0[tr], sh.Slen0[tr]); rec.y = sh.SnSet0[tr] ? n : (YB ? 0xFFFFFFFFu : 0u);      /* (YB: "never set" must read as older than every column, see the scan behind the column loop) */ \
                     yrec[roff + (4u * (g) + (uint32_t)k) * 64u + (uint32_t)lane] = rec; \
                     V.SmoveF[roff + row] = TB_NONE; V.ImoveF[roff + row] = TB_NONE; \
                     b = V.xseq[cd.seqoff + row]; \
@@ -601,12 +603,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
         // local_row1_circ); the walk learns it from bit 31 of the column's jump-table entry
         bool circ = false;
         if (CIRC) { ColCtx cc; cc.jump = ji; cc.circ_ok = (circular && !rowm_xsuf) ? 1 : 0; cc.circ_score = rowm_S; cc.circ_len = rowm_len + 1; circ = local_row1_circ(cc); }
-        if (lane == 0) { jt_idx[(size_t)c * (n + 1) + j] = ji.idx | (circ ? JT_CIRC_BIT : 0u); jt_from[(size_t)c * (n + 1) + j] = ji.from; }
         const int32_t JSW = __builtin_amdgcn_readfirstlane(word_make(ji.score, ji.len));
         const int32_t JSW1 = circ ? __builtin_amdgcn_readfirstlane(word_make(rowm_S, rowm_len + 1)) : JSW;
         // y-suffix records are kept for cells whose score reaches ybase (never for a zero word)
         const int32_t ybase = ymode_global ? gmax : vrun;
         const int32_t ythr = ybase > 0 ? (int32_t)((uint32_t)ybase << 16) : 1;
+        // (YB) the column's common word: what a cell gets that matches the read's base and takes the jump — in the contigs the read is not
+        // on (199 of cfg5's 200) that is every cell that reaches the contig's running best, a quarter of all rows in every column, and 8 bytes
+        // of record each were 4.3 of the 5.3 bytes per cell the kernel wrote there.  Such a cell's record would be {W, n - j}: a BIT says as
+        // much (bit 7 of its traceback byte, which no reader of the byte looks at), and W goes to Wcol[j] once per column.  The scan behind the
+        // column loop writes each row's LAST such record where the stores would have left it.  Off where W is below the threshold (then no
+        // cell's bit is set: the word of a row that takes no part is 0, the threshold at least 1).
+        const uint32_t Wc = YB ? (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(MW1v + JSW - 1) >= ythr ? (int32_t)(MW1v + JSW - 1) : -1) : 0xFFFFFFFFu;
+        if (lane == 0) {
+            jt_idx[(size_t)c * (n + 1) + j] = ji.idx | (circ ? JT_CIRC_BIT : 0u); jt_from[(size_t)c * (n + 1) + j] = ji.from;
+            if (YB) V.Wcol[(size_t)c * (n + 1) + j] = Wc;
+        }
 
         // (what depends only on the lane is constant over the read: the compiler would hoist the base words and the group guards out
         // of the column loop and pin registers for them; values it cannot see through keep them one LDS read / one compare each)
@@ -714,17 +726,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
         // register k of group gm holds a row below m (a row that takes part in the records) unless this is the lane of row m and
         // k <= pad (k < pad: no row at all; k == pad: row m itself)
 #define ROWM_GROUP(g) ((g) < 2 && (uint32_t)(g) == gm && mine)
+// (A/B, -DSTITCH_YREC_B64: one 64-bit store per record instead of two dword stores — half the store instructions, the same bytes: cfg5 22.6
+// against 22.9-23.3 reads/s, gpurun_out/r4yb: the records cost what their bytes cost the write path, not their issue slots)
+#ifdef STITCH_YREC_B64
+#define YREC_STORE(t, off) { u32x2 rec_; rec_.x = (t); rec_.y = ycol; __builtin_amdgcn_raw_buffer_store_b64(rec_, ryr, vo, (off), 0); }
+#else
+#define YREC_STORE(t, off) { __builtin_amdgcn_raw_buffer_store_b32((t), ryr, vo, (off), 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (off) + 4, 0); }
+#endif
 #define P2TAIL(g) \
             const uint32_t t3 = (ROWM_GROUP(g) && 3u <= pad) ? 0u : S[4 * (g) + 3], t2 = (ROWM_GROUP(g) && 2u <= pad) ? 0u : S[4 * (g) + 2]; \
             const uint32_t t1 = (ROWM_GROUP(g) && 1u <= pad) ? 0u : S[4 * (g) + 1], t0 = ROWM_GROUP(g) ? 0u : S[4 * (g)]; \
             const uint32_t g4 = (t3 > t2 ? t3 : t2) > (t1 > t0 ? t1 : t0) ? (t3 > t2 ? t3 : t2) : (t1 > t0 ? t1 : t0); \
             group_records(R, g4, (uint32_t)(g)); \
+            if (YB) {                                        /* the cells that hold the column's common word: a bit each; the others as below */ \
+                uint32_t g4u = 0u; \
+                { const bool w = t3 == Wc; tbw |= w ? 0x80000000u : 0u; const uint32_t u = w ? 0u : t3; g4u = u; } \
+                { const bool w = t2 == Wc; tbw |= w ? 0x00800000u : 0u; const uint32_t u = w ? 0u : t2; g4u = u > g4u ? u : g4u; } \
+                { const bool w = t1 == Wc; tbw |= w ? 0x00008000u : 0u; const uint32_t u = w ? 0u : t1; g4u = u > g4u ? u : g4u; } \
+                { const bool w = t0 == Wc; tbw |= w ? 0x00000080u : 0u; const uint32_t u = w ? 0u : t0; g4u = u > g4u ? u : g4u; } \
+                if (__builtin_expect((int32_t)g4u >= ythr, 0)) { \
+                    const uint32_t vo = 8u * (uint32_t)lane_x; \
+                    if ((int32_t)t3 >= ythr && t3 != Wc) { YREC_STORE(t3, (4 * (g) + 3) * 512) } \
+                    if ((int32_t)t2 >= ythr && t2 != Wc) { YREC_STORE(t2, (4 * (g) + 2) * 512) } \
+                    if ((int32_t)t1 >= ythr && t1 != Wc) { YREC_STORE(t1, (4 * (g) + 1) * 512) } \
+                    if ((int32_t)t0 >= ythr && t0 != Wc) { YREC_STORE(t0, (4 * (g)) * 512) } \
+                } \
+            } else \
             if ((int32_t)g4 >= ythr) {                       /* (two dword stores: a 64-bit one wants a register PAIR, i.e. a neighbour of the row's register saved and restored) */ \
                 const uint32_t vo = 8u * (uint32_t)lane_x; \
-                if ((int32_t)t3 >= ythr) { __builtin_amdgcn_raw_buffer_store_b32(t3, ryr, vo, (4 * (g) + 3) * 512, 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (4 * (g) + 3) * 512 + 4, 0); } \
-                if ((int32_t)t2 >= ythr) { __builtin_amdgcn_raw_buffer_store_b32(t2, ryr, vo, (4 * (g) + 2) * 512, 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (4 * (g) + 2) * 512 + 4, 0); } \
-                if ((int32_t)t1 >= ythr) { __builtin_amdgcn_raw_buffer_store_b32(t1, ryr, vo, (4 * (g) + 1) * 512, 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (4 * (g) + 1) * 512 + 4, 0); } \
-                if ((int32_t)t0 >= ythr) { __builtin_amdgcn_raw_buffer_store_b32(t0, ryr, vo, (4 * (g)) * 512, 0); __builtin_amdgcn_raw_buffer_store_b32(ycol, ryr, vo, (4 * (g)) * 512 + 4, 0); } \
+                if ((int32_t)t3 >= ythr) { YREC_STORE(t3, (4 * (g) + 3) * 512) } \
+                if ((int32_t)t2 >= ythr) { YREC_STORE(t2, (4 * (g) + 2) * 512) } \
+                if ((int32_t)t1 >= ythr) { YREC_STORE(t1, (4 * (g) + 1) * 512) } \
+                if ((int32_t)t0 >= ythr) { YREC_STORE(t0, (4 * (g)) * 512) } \
             } \
             __builtin_nontemporal_store(tbw, ((g) < 12 ? tbcol : tbcol_hi) + (((g) < 12 ? (g) : (g) - 12) * 64 + lane_x));      /* scalar base + lane offset + immediate (< 4 KB) */ \
             if ((g) < 2 && (uint32_t)(g) == gm) tbw0 = tbw;
@@ -883,6 +916,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
     RPROF(6)
     if (lane == 0) { unsigned long long* const pf = (unsigned long long*)((uint8_t*)V.err + 16); for (int k = 0; k < 8; ++k) atomicAdd(pf + k, (unsigned long long)pf_sum[k]); atomicAdd(pf + 8, 1ull); atomicAdd(pf + 9, (unsigned long long)pf_cnt[0]); atomicAdd(pf + 10, (unsigned long long)pf_cnt[1]); for (int k = 0; k < 6; ++k) atomicAdd(pf + 11 + k, (unsigned long long)pf_cls[k]); }
 #endif
+    // ---- (YB) the records that went out as bits: for every row the LAST column whose bit is set, written where the stores would have left
+    // it.  A row's records are written in column order and each replaces the one before, so the slot must end up with the later of {the
+    // 8-byte record it holds, the row's last bit}: n - j of the later is the smaller.  Columns are scanned from the last one back, a row is
+    // done at its first bit; in a contig the read is not on a quarter of the rows have their bit in any column, so the wave is through
+    // after a few dozen columns — and where W stayed below the threshold for long (the contig the read ends in) the columns without bits are
+    // skipped 64 at a time.
+    if (YB) {
+        uint32_t lane_o = threadIdx.x & 63u; asm volatile("" : "+v"(lane_o));
+        const uint32_t gl_o = gq + (lane_o < grem ? 1u : 0u), rsh_o = (grem > 0 && lane_o >= grem) ? 4u : 0u;
+        const bool has0_o = gl_o > 0 && rsh_o == 0u, mine_o = (int)lane_o == mlane;
+        const gptr<u32x2> yrec_o = (gptr<u32x2>)as_global(V.D);
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((uint8_t*)(V.Wcol + (size_t)c * (n + 1)), 0, 0x7FFFFFFF, RSRC_WORD3);
+        // bit 7 of byte k of done[g]: register 4 g + k of this lane has nothing (more) to find — no row, row m, or found
+        uint32_t done[NG]; uint32_t pending = 0;
+#define DINIT(g) { uint32_t v = ((g) == 0 ? has0_o : (gl_o > 0 && (uint32_t)(g) < gtop)) ? 0u : 0x80808080u; \
+            if ((g) < 2 && (uint32_t)(g) == gm && mine_o) v |= 0x80808080u >> (8u * (3u - pad));      /* registers 0..pad of the group: no row, and row m (its records are the epilogue's) */ \
+            done[g] = v; pending += 4u - (uint32_t)__builtin_popcount(v); }
+        REP20(DINIT)
+#undef DINIT
+        for (uint32_t jb = n; jb >= 1u && __ballot(pending != 0u) != 0ull; jb = jb > 64u ? jb - 64u : 0u) {
+            // 64 columns' common words at once, lane l holding column jb - l
+            const uint32_t wv_ = lane_o < jb ? __builtin_amdgcn_raw_buffer_load_b32(rW, 4u * (jb - lane_o), 0, 0) : 0xFFFFFFFFu;
+            unsigned long long cols = __ballot(wv_ != 0xFFFFFFFFu);
+            while (cols != 0ull && __ballot(pending != 0u) != 0ull) {
+                const int l = (int)__builtin_ctzll(cols); cols &= cols - 1ull;
+                const uint32_t j = jb - (uint32_t)l, Wj = (uint32_t)__builtin_amdgcn_readlane((int)wv_, l), yc = n - j;
+                const __amdgpu_buffer_rsrc_t rtbj = __builtin_amdgcn_make_buffer_rsrc(tb0 + (size_t)(j - 1) * Rtot, 0, 0x7FFFFFFF, RSRC_WORD3);
+#define SCAN(g) if ((uint32_t)(g) < gtop) { \
+                    const uint32_t nb = __builtin_amdgcn_raw_buffer_load_b32(rtbj, 4u * lane_o, (g) * 256, 0) & 0x80808080u & ~done[g]; \
+                    if (nb != 0u) { \
+                        _Pragma("unroll") for (int k = 0; k < 4; ++k) if (nb & (0x80u << (8 * k))) { \
+                            const uint32_t at = roff + (4u * (g) + (uint32_t)k) * 64u + lane_o; \
+                            if (yrec_o[at].y > yc) { u32x2 rec; rec.x = Wj; rec.y = yc; yrec_o[at] = rec; } \
+                        } \
+                        done[g] |= nb; pending -= (uint32_t)__builtin_popcount(nb); \
+                    } }
+                REP20(SCAN)
+#undef SCAN
+            }
+        }
+    }
     // ---- unpack the y-suffix records of this wave's rows into the arrays the fix-up kernel reads (its own stores: no barrier) -------
     // (the lane's geometry worked out afresh from a lane number the compiler cannot trace back: what it would otherwise carry through the
     // column loop for this epilogue — addresses, row counts — it had to spill to scratch memory, which a persistent launch must not use)
@@ -896,7 +970,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
             const uint32_t row = rowbase_o + (nrows_o - 1 - i);
             if (row < m) {
                 const u32x2 rec = yrec_o[roff + (i + rsh_o) * 64u + lane_o];
-                V.Sn[roff + row] = word_score((int32_t)rec.x); V.SnLen[roff + row] = word_len((int32_t)rec.x); V.Ly[roff + row] = rec.y;
+                V.Sn[roff + row] = word_score((int32_t)rec.x); V.SnLen[roff + row] = word_len((int32_t)rec.x); V.Ly[roff + row] = (YB && rec.y == 0xFFFFFFFFu) ? 0u : rec.y;
             }
         }
     }
@@ -917,7 +991,8 @@ uint32_t fill_regs_rows_per_wave() { return 64u * RMAX; }
 // workgroups of `waves` waves one CU holds at once, as the runtime's occupancy calculator sees it (the host never launches more
 // workgroups than CUs x this: all workgroups of a read must be resident, they wait for each other every column)
 int fill_regs_workgroups_per_cu(uint32_t waves) {
-    const void* kernels[4] = {(const void*)fill_regs_kernel<1, false>, (const void*)fill_regs_kernel<4, false>, (const void*)fill_regs_kernel<1, true>, (const void*)fill_regs_kernel<4, true>};
+    const void* kernels[8] = {(const void*)fill_regs_kernel<1, false, false>, (const void*)fill_regs_kernel<4, false, false>, (const void*)fill_regs_kernel<1, true, false>, (const void*)fill_regs_kernel<4, true, false>,
+                              (const void*)fill_regs_kernel<1, false, true>, (const void*)fill_regs_kernel<4, false, true>, (const void*)fill_regs_kernel<1, true, true>, (const void*)fill_regs_kernel<4, true, true>};
     int least = 1 << 30;
     for (const void* k : kernels) {
         // (more than 64 KiB of dynamic LDS has to be allowed explicitly)
@@ -930,10 +1005,12 @@ int fill_regs_workgroups_per_cu(uint32_t waves) {
 }
 // max_nact: the largest number of active contigs of any job of the launch; circular: opts.circular
 // q == nullptr: a classic launch (wave_map[w].x = the job); else persistent teams that pull jobs off the queue (wave_map[w].x = the team)
-void launch_fill_regs(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, const StreamCtl* q, hipStream_t stream) {
+void launch_fill_regs(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t waves, uint32_t max_nact, bool circular, bool ybits, const FillShared& sh, const StreamCtl* q, hipStream_t stream) {
     const dim3 grid((n_waves + waves - 1) / waves), block(waves * 64); const size_t lds = (size_t)waves * LDS_PER_WAVE;
-    if (max_nact <= 64) { if (circular) hipLaunchKernelGGL((fill_regs_kernel<1, true>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves, q); else hipLaunchKernelGGL((fill_regs_kernel<1, false>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves, q); }
-    else { if (circular) hipLaunchKernelGGL((fill_regs_kernel<4, true>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves, q); else hipLaunchKernelGGL((fill_regs_kernel<4, false>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves, q); }
+#define GO(NQ_, CIRC_, YB_) hipLaunchKernelGGL((fill_regs_kernel<NQ_, CIRC_, YB_>), grid, block, lds, stream, d_jobs, sh, d_wave_map, n_waves, q)
+    if (max_nact <= 64) { if (circular) { if (ybits) GO(1, true, true); else GO(1, true, false); } else { if (ybits) GO(1, false, true); else GO(1, false, false); } }
+    else { if (circular) { if (ybits) GO(4, true, true); else GO(4, true, false); } else { if (ybits) GO(4, false, true); else GO(4, false, false); } }
+#undef GO
 }
 
 }  // namespace stitch

@@ -60,7 +60,7 @@ constexpr size_t PIN_BYTES = (size_t)64 << 20;   // pinned staging buffer for re
 constexpr uint32_t TILE_ROWS = 512;   // 64 lanes x 8 rows (Local-mode kernel; the generic one uses 256): contig row blocks are padded to this
 void launch_fill_local16(const JobView* d_jobs, uint32_t n_jobs, uint32_t G, int waves, uint32_t slots_cap, const FillShared& sh, hipStream_t stream);
 uint32_t fill_local16_max_slots();
-void launch_fill_regs(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t waves, uint32_t max_nact, bool circular, const FillShared& sh, const StreamCtl* q /* device copy; nullptr = classic launch */, hipStream_t stream);
+void launch_fill_regs(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t waves, uint32_t max_nact, bool circular, bool ybits, const FillShared& sh, const StreamCtl* q /* device copy; nullptr = classic launch */, hipStream_t stream);
 uint32_t fill_regs_rows_per_wave();
 int fill_regs_workgroups_per_cu(uint32_t waves);
 void launch_fill_regs32(const JobView* d_jobs, const uint2* d_wave_map, uint32_t n_waves, uint32_t max_nact, bool circular, const FillShared& sh, hipStream_t stream);
@@ -93,6 +93,7 @@ struct Job {                                     // one full jump DP
 
 // Diagnostic / experiment knobs, read from the environment ONCE when a context is created (never per launch).
 struct Knobs {
+    bool no_ybits = false;
     bool fail_first_attempt = false;             // test hook: treat the first attempt of every cooperative launch as timed out
     bool fail_keeps_pipeline = false;            // test hook ("pipelined"): ... and keep two fills in flight, so that a repeat runs beside the other window's fill
     bool debug = false, force_generic = false, profile_dump = false, banded_global = false, fill_only = false, no_regs = false, no_regs32 = false, force_regs32 = false, no_pipeline = false, no_fill_overlap = false, prealign_v1 = false, host_bands = false;
@@ -121,6 +122,7 @@ struct Knobs {
         k.regs_waves = (int)num("STITCH_REGS_WAVES"); k.regs_map = (int)num("STITCH_REGS_MAP"); k.trace = getenv("STITCH_TRACE") != nullptr;
         k.no_wg_poll = getenv("STITCH_NO_WG_POLL") != nullptr;    // every wave polls its team's granules itself even where a workgroup's waves are one team's (A/B runs)
         k.prealign_general = getenv("STITCH_PREALIGN_GENERAL") != nullptr;      // (tests) the filter's general path (every mode, 32-bit band ranges) also where the fast Local path applies
+        k.no_ybits = getenv("STITCH_NO_YBITS") != nullptr;      // per-contig y-suffix records all as 8-byte records, none as a bit of the traceback byte (A/B runs, tests)
         k.no_join = getenv("STITCH_NO_JOIN") != nullptr;          // traceback_all: every chain walked to its start (A/B runs, tests), none joined to the reference chain
         k.no_stream = getenv("STITCH_NO_STREAM") != nullptr;
         // Under rocprofv3 (kernel trace or counters) a launch beside resident teams is not reported complete until the teams' own dispatch
@@ -401,7 +403,7 @@ namespace {
 struct JobLayout {
     uint32_t n, nact, Rj, slots, ops_cap;
     size_t off_S, off_Slen, off_D, off_Dlen, off_Sn, off_SnLen, off_Ly, off_Ival, off_Ilen, off_SidxF, off_SfromF, off_SmoveF, off_ImoveF,
-        off_st16, off_xchg, off_tb, off_Lx, off_jti, off_jtf, off_Sm, off_Lm, off_visit, off_y, off_act, off_opp, off_cd, off_hdr, off_ops, bytes,
+        off_st16, off_xchg, off_tb, off_Lx, off_jti, off_jtf, off_Sm, off_Lm, off_visit, off_Wcol, off_y, off_act, off_opp, off_cd, off_hdr, off_ops, bytes,
         stride;              // distance to the next job's block in a launch (bytes rounded up to the launch's block alignment)
 };
 
@@ -430,6 +432,7 @@ JobLayout layout_job(const stitch_ctx& c, const Job& jb) {
     L.off_tb = take_big((size_t)L.n * R);
     L.off_Lx = take(4ull * c.C * (L.n + 1)); L.off_jti = take(4ull * c.C * (L.n + 1)); L.off_jtf = take(4ull * c.C * (L.n + 1));
     L.off_Sm = take(4ull * c.C); L.off_Lm = take(4ull * c.C);
+    L.off_Wcol = take(jb.mode != 0 ? 4ull * c.C * (L.n + 1) : 0);      // the column's common word of every contig (fill_regs.hip: y-suffix records as one bit per cell)
     L.off_visit = take(jb.mode == 1 ? sizeof(VisitRec) * ((size_t)L.n + 2) : 0);      // traceback_all: the reference walk's column records (walk_core.h)
     L.off_y = take(L.n); L.off_act = take(4ull * L.nact); L.off_opp = take(4ull * c.C); L.off_cd = take(sizeof(ContigDesc) * (size_t)c.C);
     L.off_hdr = take(sizeof(ChainHdr) * (size_t)L.slots); L.off_ops = take(sizeof(OpRec) * (size_t)L.slots * L.ops_cap);
@@ -789,6 +792,7 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
         V.Smove0 = c.d_Smove0; V.Imove0 = c.d_Imove0; V.Slen0 = c.d_Slen0;
         V.Sm = (int32_t*)(Bk + L.off_Sm); V.Lm = (uint32_t*)(Bk + L.off_Lm);
         V.visit = (jb.mode == 1 && !c.knobs.no_join) ? (VisitRec*)(Bk + L.off_visit) : nullptr;
+        V.Wcol = jb.mode != 0 ? (uint32_t*)(Bk + L.off_Wcol) : nullptr;
         WalkArgs& A = wargs[k]; A.hdr = (ChainHdr*)(Bk + L.off_hdr); A.ops = (OpRec*)(Bk + L.off_ops); A.ops_cap = L.ops_cap; A.mode = jb.mode; A.from = jb.from; A.skip_fixup = 0;
         c.tm.cells += (uint64_t)L.n * [&] { uint64_t s2 = 0; for (uint32_t a : jb.act) s2 += c.al[a].m; return s2; }();
     }
@@ -827,7 +831,9 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
     std::atomic_thread_fence(std::memory_order_seq_cst);
     hipEvent_t* const ev = c.evp[0];
     HIP_TRY(hipEventRecord(ev[0], sA));
-    launch_fill_regs(d_views, d_wave_map, (uint32_t)wave_map.size(), c.regs_waves, W, c.opts.circular != 0, sh, d_ctl, sA);
+    bool ybits = !c.knobs.no_ybits;                    // (every job keeps per-contig y-suffix records: one bit per cell for the column's common word)
+    for (size_t k = 0; k < N; ++k) if (jobs[k].mode == 0) ybits = false;
+    launch_fill_regs(d_views, d_wave_map, (uint32_t)wave_map.size(), c.regs_waves, W, c.opts.circular != 0, ybits, sh, d_ctl, sA);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[1], sA));
     c.tm.fill_kind = 2u; c.tm.wg_per_read = (W + c.regs_waves - 1) / c.regs_waves; c.tm_wg_per_read = c.tm.wg_per_read;
@@ -1209,6 +1215,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
             V.Smove0 = c.d_Smove0; V.Imove0 = c.d_Imove0; V.Slen0 = c.d_Slen0;
             V.Sm = (int32_t*)(B + L.off_Sm); V.Lm = (uint32_t*)(B + L.off_Lm);
             V.visit = (jb.mode == 1 && !c.knobs.no_join) ? (VisitRec*)(B + L.off_visit) : nullptr;
+            V.Wcol = jb.mode != 0 ? (uint32_t*)(B + L.off_Wcol) : nullptr;
             WalkArgs& A = wargs[q]; A.hdr = (ChainHdr*)(B + L.off_hdr); A.ops = (OpRec*)(B + L.off_ops); A.ops_cap = L.ops_cap; A.mode = jb.mode; A.from = jb.from; A.skip_fixup = 0;
             c.tm.cells += (uint64_t)L.n * [&] { uint64_t s = 0; for (uint32_t a : jb.act) s += c.al[a].m; return s; }();
         }
@@ -1294,7 +1301,7 @@ static int run_jobs_in_order(stitch_ctx& c, std::vector<Job>& jobs) {
         const uint32_t kind = regs_G ? 2u : regs32_G ? 3u : fast ? 1u : 0u;
         Ln.G = G; Ln.kind = kind; Ln.waves = waves; Ln.slots_cap = slots_cap; Ln.g_min = g_min;
         if (kind == 3u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs32(d_views, d_wave_map, (uint32_t)wave_map.size(), mx, c.opts.circular != 0, sh, sA); }
-        else if (kind == 2u) { uint32_t mx = 0; for (uint32_t q = 0; q < nj; ++q) mx = std::max(mx, lay[k0 + q].nact); launch_fill_regs(d_views, d_wave_map, (uint32_t)wave_map.size(), c.regs_waves, mx, c.opts.circular != 0, sh, nullptr, sA); }
+        else if (kind == 2u) { uint32_t mx = 0; bool ybits = !c.knobs.no_ybits; for (uint32_t q = 0; q < nj; ++q) { mx = std::max(mx, lay[k0 + q].nact); if (jobs[k0 + q].mode == 0) ybits = false; } launch_fill_regs(d_views, d_wave_map, (uint32_t)wave_map.size(), c.regs_waves, mx, c.opts.circular != 0, ybits, sh, nullptr, sA); }
         else if (kind == 1u) launch_fill_local16(d_views, nj, G, waves, slots_cap, sh, sA);
         else launch_fill(d_views, nj, waves, sh, sA);
         HIP_TRY(hipGetLastError());

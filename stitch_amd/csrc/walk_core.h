@@ -76,6 +76,7 @@ struct JobView {
     // per-contig results of the fix-ups
     int32_t* Sm; uint32_t* Lm;                        // [C] S[n%2][m] and cell(m,n).S.len
     VisitRec* visit;                                  // [n + 2] traceback_all: the reference walk's column records (nullptr: walks do not join)
+    uint32_t* Wcol;                                   // [C][n+1] fill_regs.hip, jobs with per-contig y-suffix records: the column's common word (nullptr: none kept)
 };
 
 struct WalkArgs { ChainHdr* hdr; OpRec* ops; uint32_t ops_cap; int32_t mode; uint32_t from; uint32_t skip_fixup; };   // per job

@@ -32,6 +32,7 @@ def draw(seed):
     if os.environ.get("FUZZ_STREAM"):      # persistent teams (stitch_api.cpp run_jobs_streaming): few teams, few arena blocks, many reads, every one checked
         env = {"STITCH_REGS_MIN_ROWS": "0", "STITCH_STREAM_TEAMS": str(rng.choice([1, 2, 3, 5])), "STITCH_STREAM_BLOCKS": str(rng.choice([2, 3, 4, 9]))}
         nreads = rng.choice([9, 17, 40]); n_check = nreads
+    if os.environ.get("FUZZ_REGS"): env = dict(env, STITCH_REGS_MIN_ROWS="0")      # every eligible read on fill_regs.hip, launch by launch unless FUZZ_STREAM
     big = [t for t in targets if len(t[1]) > 30] or targets
     reads = [chimera(rng, big, rng.randint(20, rng.choice([200, 900, 1600])), err=rng.choice([0.02, 0.08]), both=double) for _ in range(nreads)]
     return targets, reads, opts, n_check, env, lens
