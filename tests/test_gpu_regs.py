@@ -135,3 +135,23 @@ def test_a_repeated_launch_beside_the_other_windows_fill(monkeypatch):
     al = P.run_pair(targets, reads)
     tm = al.timing()
     assert tm["launches"] > 2 and tm["fallbacks"] >= 2, tm
+
+
+def test_one_bit_y_suffix_records_equal_the_eight_byte_ones(monkeypatch):
+    """--suboptimal / --circular launches run the YB instances of fill_regs_kernel (a cell that holds the column's common word sets bit 7 of
+    its traceback byte instead of storing an 8-byte y-suffix record; the scan behind the column loop writes each row's last one): the same
+    chains as with every record stored (STITCH_NO_YBITS), and as the oracle — reads on their contig, chimeras, and reads that match nothing
+    (every cell the jump candidate: all bits, no records)"""
+    monkeypatch.setenv("STITCH_REGS_MIN_ROWS", "0")
+    rng = random.Random(4242)
+    targets = [(f"c{k}", P.rand_seq(rng, n)) for k, n in enumerate([900, 260, 1400, 333, 70])]
+    reads = [P.chimera(rng, targets[:4], rng.randint(80, 700), both=False) for _ in range(10)] + [P.rand_seq(rng, 300), targets[2][1][100:900]]
+    for opts in (dict(suboptimal=True), dict(suboptimal=True, circular=True), dict(circular=True)):
+        al = P.run_pair(targets, reads, **opts)
+        assert al.timing()["fill_kind"] == 2
+        got = [[c.key() for c in r[0]] for r in al.align(reads)]
+        monkeypatch.setenv("STITCH_NO_YBITS", "1")
+        al2 = stitch_amd.Builder(**opts).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in targets])
+        want = [[c.key() for c in r[0]] for r in al2.align(reads)]
+        monkeypatch.delenv("STITCH_NO_YBITS")
+        assert got == want, opts
