@@ -137,6 +137,7 @@ def main():
     cells = 0
     launches = 0
     fallbacks = 0
+    retired = 0
     stream_runs = 0
     mapped = 0
     n_mine = 0
@@ -145,7 +146,7 @@ def main():
         rr, ch, _ops = aligners.align_packed_raw(*batches[s])       # result arena views: what a compiled front end would read
         tm = aligners.timing()
         fill_ms += tm["fill_ms"]; walk_ms += tm["walk_ms"]; cells += tm["cells"]; launches += tm["launches"]; fill_kernel_ms += tm.get("fill_kernel_ms", tm["fill_ms"])
-        clk_cycles += tm.get("clk_shader_cycles", 0); clk_ticks += tm.get("clk_ref_ticks", 0); fallbacks += tm.get("fallbacks", 0); stream_runs += tm.get("stream_runs", 0)
+        clk_cycles += tm.get("clk_shader_cycles", 0); clk_ticks += tm.get("clk_ref_ticks", 0); fallbacks += tm.get("fallbacks", 0); retired += tm.get("teams_retired", 0); stream_runs += tm.get("stream_runs", 0)
         kernel_name = FILL_KERNELS.get(tm.get("fill_kind", 1), kernel_name)
         n_mine += my_reads[s]
         if len(ch):
@@ -203,7 +204,7 @@ def main():
                          "launches_in_flight": fill_kernel_ms / fill_ms if fill_ms > 0 else 1.0, "walk_kernel_ms_per_step": walk_ms / args.steps,
                          "fill_gcells_per_sec": cells / fill_s / 1e9 if fill_s > 0 else 0.0,
                          # launches repeated on a slower kernel after a partner timeout (co-residency lost): must be 0 in a healthy run
-                         "fill_fallbacks": fallbacks,
+                         "fill_fallbacks": fallbacks, "teams_retired": retired,
                          # how the fill was launched: one dispatch per step whose teams pull reads off a queue ("persistent teams"), or launch by
                          # launch with two fills in flight (STITCH_NO_STREAM=1, and always under rocprofv3, which reports a launch beside
                          # resident teams complete only when they are: DESIGN.md 4)

@@ -107,7 +107,9 @@ typedef struct stitch_timing { double fill_ms, walk_ms, h2d_ms, d2h_ms, host_ms;
                                   (s_memrealtime) over the column loop of the first read of every launch, summed: cycles / ticks x 100 = MHz */;
                                double fill_kernel_ms /* sum of the fill kernels' own durations (what a profiler lists per dispatch).  fill_ms is the time during
                                   which a fill kernel was RUNNING: with two launches in flight (the next one takes the slots finished reads free) the
-                                  two differ */; } stitch_timing;
+                                  two differ */;
+                               uint32_t teams_retired /* persistent teams asked to leave early because a launch beside them waited beyond its bound (each frees
+                                  its wave slots for the rest of the call; 0 in nearly every call) */, reserved_; } stitch_timing;
 /* `out_size` = sizeof(stitch_timing) as the CALLER was compiled: the library copies min(out_size, its own size) bytes, so the struct can
  * grow at its end without overrunning a binding built against an older header (fields are only ever appended). */
 int stitch_last_timing(const stitch_ctx*, stitch_timing* out, size_t out_size);

@@ -55,7 +55,7 @@ class _Timing(C.Structure):  # == stitch_timing
     _fields_ = [("fill_ms", C.c_double), ("walk_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
                 ("host_ms", C.c_double), ("cells", C.c_uint64), ("launches", C.c_uint32), ("jobs", C.c_uint32),
                 ("prealign_ms", C.c_double), ("prealign_host_ms", C.c_double), ("fill_kind", C.c_uint32), ("wg_per_read", C.c_uint32), ("fallbacks", C.c_uint32), ("stream_runs", C.c_uint32),
-                ("clk_shader_cycles", C.c_uint64), ("clk_ref_ticks", C.c_uint64), ("fill_kernel_ms", C.c_double)]
+                ("clk_shader_cycles", C.c_uint64), ("clk_ref_ticks", C.c_uint64), ("fill_kernel_ms", C.c_double), ("teams_retired", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 EXPORTS = ("stitch_opts_default", "stitch_index_build", "stitch_index_serialize", "stitch_index_deserialize",

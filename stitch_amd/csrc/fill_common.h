@@ -19,11 +19,11 @@ struct FillShared {              // column-0 state of every aligner, evaluated o
 // (system-scope accesses, never cached on the device); the queue head, the per-job wave counters and the teams' mailboxes are
 // device memory touched with agent-scope accesses only, like the column granules.
 struct StreamCtl {
-    uint32_t* next;                     // device: the next job to hand out
+    uint32_t* next;                     // device: the next job to hand out ([16]: teams that have left on the host's request)
     uint32_t* cnt;                      // device [n_jobs]: waves of the job that have stored all their results
     unsigned long long* mbox;           // device [teams]: {sequence number, job} announced by a team's first wave
     uint32_t* h_ready;                  // pinned host: jobs below this number may start (the arena block they use is free again)
-    uint32_t* h_abort;                  // pinned host: non-zero = hand out no more jobs
+    uint32_t* h_abort;                  // pinned host: 0 = carry on, 1 .. 2^31 - 1 = so many teams leave at their next read, above = hand out no more jobs
     uint32_t* h_done;                   // pinned host [n_jobs]: set by the last wave of a job once every wave's results are written back
     uint32_t* h_err;                    // pinned host: set by a wave that gave up waiting (partner, mailbox or block)
     uint32_t n_jobs;

@@ -284,7 +284,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
         uint32_t idx = 0xFFFFFFFFu;
         if (kmine == 0u) {
             if (lane0 == 0) {
-                if (__hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) idx = atomicAdd(q.next, 1u);
+                // the host's word: 0 = carry on; 1 .. 2^31 - 1 = that many teams are asked to LEAVE (a launch beside the teams waits for a wave slot
+                // where the dispatcher put it: the first teams to come by take a ticket each and go, the others carry on); above = hand out no more jobs
+                const uint32_t ab = __hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                bool go = ab == 0u;
+                if (ab != 0u && ab < 0x80000000u) { if (atomicAdd(q.next + 16, 1u) < ab) go = false; else { atomicSub(q.next + 16, 1u); go = true; } }
+                if (go) idx = atomicAdd(q.next, 1u);
                 if (idx >= q.n_jobs) idx = 0xFFFFFFFFu;
                 // The job's arena block is the one job - blocks used: wait until the host has walked that read and taken its chains.  ONE lane
                 // of the team looks at the host's word, and not often: it lives in pinned host memory, every look is a trip over PCIe (a whole
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
                     const uint32_t t0 = (uint32_t)wall_clock64();
                     for (uint32_t spins = 1;; ++spins) {
                         if (__hip_atomic_load(q.h_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > idx) break;
-                        if ((spins & 7u) == 0 && (__hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || (uint32_t)wall_clock64() - t0 > 4000000000u)) { idx = 0xFFFFFFFFu; break; }
+                        if ((spins & 7u) == 0 && (__hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= 0x80000000u || (uint32_t)wall_clock64() - t0 > 4000000000u)) { idx = 0xFFFFFFFFu; break; }
                         for (int k = 0; k < 6; ++k) __builtin_amdgcn_s_sleep(127);      // ~20 us between two looks
                     }
                 }

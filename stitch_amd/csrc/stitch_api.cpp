@@ -100,7 +100,7 @@ struct Knobs {
     size_t array_align = 0, job_align = 0;
     std::string dump_dir;                        // (debugging) column-n arrays of every job as the fill left them, one file per job
     int max_waves = 0, wg_per_read = 0, tiles_per_wave = 0; long regs_min_rows = -1;
-    int regs_waves = 0, regs_map = 0; bool trace = false, no_stream = false, no_join = false, no_wg_poll = false, prealign_general = false; int stream_blocks = 0, stream_teams = 0, stream_range = 0; bool test_stream_stall = false;      // (experiments) waves per workgroup of fill_regs.hip, order of its wave map; launch timeline on stderr
+    int regs_waves = 0, regs_map = 0; bool trace = false, no_stream = false, no_join = false, no_wg_poll = false, prealign_general = false; int stream_blocks = 0, stream_teams = 0, stream_range = 0; bool test_stream_retire = false; bool test_stream_stall = false;      // (experiments) waves per workgroup of fill_regs.hip, order of its wave map; launch timeline on stderr
     static Knobs from_env() {
         Knobs k;
         auto num = [](const char* name) -> unsigned long long { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : 0ull; };
@@ -132,6 +132,7 @@ struct Knobs {
         { const char* pre = getenv("LD_PRELOAD"); if (getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || (pre && strstr(pre, "rocprofiler"))) k.no_stream = true; }      // launch by launch even where persistent teams apply (A/B runs, tests)
         k.stream_blocks = (int)num("STITCH_STREAM_BLOCKS");       // (tests) cap on the arena blocks of a persistent-team run
         k.stream_range = (int)num("STITCH_STREAM_RANGE");         // (experiments) most jobs walked by one fix-up + walk launch
+        k.test_stream_retire = getenv("STITCH_TEST_STREAM_RETIRE") != nullptr;      // (tests) the first bounded wait of a run asks one team to leave
         k.test_stream_stall = getenv("STITCH_TEST_STREAM_STALL") != nullptr;      // (tests) the first bounded wait beside resident teams counts as a stall: the run is called off
         k.stream_teams = (int)num("STITCH_STREAM_TEAMS");         // (tests) ... and on its teams, so that small batches queue up behind few teams
         if (const char* e = getenv("STITCH_REGS_MIN_ROWS")) k.regs_min_rows = atol(e);     // (tests: 0 sends every eligible read to fill_regs.hip)
@@ -181,6 +182,8 @@ struct stitch_ctx {
     bool in_stream_fallback = false;             // run_jobs_streaming is on the stack (its fallback goes launch by launch)
     uint32_t* stream_abort_word = nullptr;        // persistent teams running: the pinned word that calls the run off (set by bounded_sync when a launch beside them does not end)
     bool stream_stalled = false;                 // ... and that it happened
+    uint32_t stream_retired = 0, stream_may_retire = 0;      // teams of the current run asked to leave early (bounded_sync), and how many may be (never the last one)
+    double stream_bound_s = 0.25;                // how long a launch beside the teams may take before one is asked to
     bool warmed_up = false;                      // a classic launch of the register-resident fill with its walk and downloads has completed in this context
     size_t mem_limit = 0;                        // optional cap on arena bytes (STITCH_ARENA_BYTES), for tests
     // banded pre-alignment filter (prealign.h): host copies of the contig strands, their k-mer indexes, device scratch
@@ -531,15 +534,26 @@ int pick_waves(const stitch_ctx& c, uint32_t nact, int maxw) {          // fewes
 // (the teams leave after the read they are on, the stuck launch then runs) and what is left goes launch by launch.
 static int bounded_sync(stitch_ctx& c, hipStream_t s) {
     if (!c.stream_abort_word) { HIP_TRY(hipStreamSynchronize(s)); return STITCH_OK; }
-    const auto t0 = std::chrono::steady_clock::now();
+    // First a quarter of a second, then ONE team is asked to leave (the first that comes to the end of its read goes, which frees its wave
+    // slots for the rest of the call: the stuck workgroup runs, the other teams never notice), up to three times; only then, or 1.5 s after
+    // the last request, the whole run is called off.
+    auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
         if (e == hipSuccess) return STITCH_OK;
         if (e != hipErrorNotReady) return fail(STITCH_EDEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e));
-        if ((std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 1.5 || c.knobs.test_stream_stall) && !c.stream_stalled) {
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (!c.stream_stalled && (c.knobs.test_stream_stall || (c.stream_retired >= c.stream_may_retire && waited > 1.5))) {
             c.stream_stalled = true;
-            *(volatile uint32_t*)c.stream_abort_word = 1u;
+            *(volatile uint32_t*)c.stream_abort_word = 0xFFFFFFFFu;
             std::atomic_thread_fence(std::memory_order_seq_cst);
+        }
+        else if (!c.stream_stalled && c.stream_retired < c.stream_may_retire && (waited > c.stream_bound_s || (c.knobs.test_stream_retire && c.stream_retired == 0))) {
+            c.stream_retired += 1; c.tm.teams_retired += 1;
+            *(volatile uint32_t*)c.stream_abort_word = c.stream_retired;
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+            if (c.knobs.trace) fprintf(stderr, "[trace] a launch beside the teams has waited %.0f ms: team %u asked to leave\n", waited * 1e3, c.stream_retired);
+            t0 = std::chrono::steady_clock::now();
         }
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
@@ -826,7 +840,8 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
     HIP_TRY(hipStreamSynchronize(sB));
     c.tm.h2d_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h2d0).count();
     if (const char* e = getenv("STITCH_STREAM_SETTLE_MS")) { HIP_TRY(hipDeviceSynchronize()); std::this_thread::sleep_for(std::chrono::milliseconds(atoi(e))); }      // (experiment)
-    c.stream_abort_word = c.pin_q + 16; c.stream_stalled = false;
+    c.stream_abort_word = c.pin_q + 16; c.stream_stalled = false; c.stream_retired = 0; c.stream_may_retire = (uint32_t)std::min<size_t>(3, T > 0 ? T - 1 : 0);
+    if (const char* e = getenv("STITCH_STREAM_BOUND_MS")) c.stream_bound_s = std::max(1, atoi(e)) * 1e-3;
     hq[0] = (uint32_t)std::min(N, B);                  // the first B jobs find their blocks free
     std::atomic_thread_fence(std::memory_order_seq_cst);
     hipEvent_t* const ev = c.evp[0];
@@ -893,7 +908,7 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
         t_last = std::chrono::steady_clock::now();
     }
     if (c.stream_stalled) broken = true;
-    if (broken) { hq[16] = 1u; std::atomic_thread_fence(std::memory_order_seq_cst); }
+    if (broken) { hq[16] = 0xFFFFFFFFu; std::atomic_thread_fence(std::memory_order_seq_cst); }
     c.stream_abort_word = nullptr;
     HIP_TRY(hipStreamSynchronize(sA));                  // (every team leaves once the queue is empty or called off; every wait in the kernel is bounded)
     { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); c.tm.fill_ms += ms; c.tm.fill_kernel_ms += ms; }

@@ -102,7 +102,7 @@ def main():
     dt = time.perf_counter() - t0 - t_check
     out = {"config": args.config, "mode": args.mode, "fill_kind": al.timing().get("fill_kind"), "reads": len(reads), "batch": batch, "seconds": dt, "reads_per_sec": len(reads) / dt,
            "gcells_per_sec": tot["cells"] / dt / 1e9, "chains": n_chains, "chains_whose_ops_do_not_rescore": None if args.config == "cfg5" else n_bad,
-           "reads_with_chains": mapped, "results_sha256": digest.hexdigest()[:16], "stream_runs": al.timing().get("stream_runs"), "fallbacks": al.timing().get("fallbacks"), **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in tot.items()}}
+           "reads_with_chains": mapped, "results_sha256": digest.hexdigest()[:16], "stream_runs": al.timing().get("stream_runs"), "fallbacks": al.timing().get("fallbacks"), "teams_retired": al.timing().get("teams_retired"), **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in tot.items()}}
 
     if args.config == "cfg1":                                                  # small enough for the oracle: full comparison
         from oracle import oracle as orc

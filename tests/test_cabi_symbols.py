@@ -29,7 +29,7 @@ def test_exports_match_header():
 def test_struct_sizes_match_header():
     assert C.sizeof(api._Op) == 8 and C.sizeof(api._Chain) == 56 and C.sizeof(api._ReadResult) == 24
     assert C.sizeof(api._Opts) == 24 * 4
-    assert C.sizeof(api._Timing) == 112
+    assert C.sizeof(api._Timing) == 120
 
 
 _CT = {"int32_t": C.c_int32, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64, "uint16_t": C.c_uint16, "uint8_t": C.c_uint8,

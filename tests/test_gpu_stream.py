@@ -101,6 +101,25 @@ def test_a_chain_beyond_its_buffer_ends_the_run_and_the_classic_path_finishes(mo
     P.run_pair(targets, reads, gap_open=0, gap_extend=-1, check_sam=False)
 
 
+def test_a_slow_launch_beside_the_teams_retires_one_team(monkeypatch):
+    """a launch beside the teams that waits beyond its (short) bound: ONE team is asked to leave — the first to reach the end of its read
+    takes the ticket and frees its wave slots — and the others finish the queue; nothing is repeated (test hook: the first wait of the run
+    counts as slow)"""
+    monkeypatch.setenv("STITCH_TEST_STREAM_RETIRE", "1")
+    monkeypatch.setenv("STITCH_STREAM_TEAMS", "3")
+    rng = random.Random(78)
+    targets = [(f"c{k}", P.rand_seq(rng, n)) for k, n in enumerate([800, 500, 900])]
+    reads = [P.chimera(rng, targets, rng.randint(80, 400), both=False) for _ in range(24)]
+    al = P.run_pair(targets, reads)
+    tm = al.timing()
+    assert tm["stream_runs"] == 1 and tm["fallbacks"] == 0 and tm["teams_retired"] == 1, tm
+    # one team only: nobody may be asked to leave (the queue would never empty), the bound then calls the run off as before
+    monkeypatch.setenv("STITCH_STREAM_TEAMS", "1")
+    al = P.run_pair(targets, reads[:9])
+    tm = al.timing()
+    assert tm["teams_retired"] == 0 and tm["fallbacks"] == 0, tm
+
+
 def test_a_stalled_launch_beside_the_teams_calls_the_run_off(monkeypatch):
     """a fix-up / walk launch (or a copy) beside resident teams that does not end within its bound: the host calls the run off, the teams
     leave after the read they are on, and what is left goes launch by launch (test hook: the first wait counts as a stall)"""
