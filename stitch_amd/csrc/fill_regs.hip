@@ -284,23 +284,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STITCH_REGS
         uint32_t idx = 0xFFFFFFFFu;
         if (kmine == 0u) {
             if (lane0 == 0) {
-                // the host's word: 0 = carry on; 1 .. 2^31 - 1 = that many teams are asked to LEAVE (a launch beside the teams waits for a wave slot
-                // where the dispatcher put it: the first teams to come by take a ticket each and go, the others carry on); above = hand out no more jobs
-                const uint32_t ab = __hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                bool go = ab == 0u;
-                if (ab != 0u && ab < 0x80000000u) { if (atomicAdd(q.next + 16, 1u) < ab) go = false; else { atomicSub(q.next + 16, 1u); go = true; } }
-                if (go) idx = atomicAdd(q.next, 1u);
-                if (idx >= q.n_jobs) idx = 0xFFFFFFFFu;
-                // The job's arena block is the one job - blocks used: wait until the host has walked that read and taken its chains.  ONE lane
-                // of the team looks at the host's word, and not often: it lives in pinned host memory, every look is a trip over PCIe (a whole
+                // The job's arena block is the one job - blocks used: the team waits until the host has walked that read and taken its chains, and
+                // it takes the job off the queue only THEN — a team that waits holds no job, so it can leave when the host asks teams to.  ONE lane
+                // of the team looks at the host's words, and not often: they live in pinned host memory, every look is a trip over PCIe (a whole
                 // team looking — 200 waves every 3 us at cfg5, where a run has few spare blocks and teams wait as a rule — slowed every fill
                 // wave and every copy of the process five-fold: gpurun_out/r4j).  Bounded: 40 s; the host ends a run that makes no progress
-                // earlier and says so through h_abort.  The team's other waves wait for the mailbox, i.e. in device memory.
-                if (idx != 0xFFFFFFFFu) {
+                // earlier.  The team's other waves wait for the mailbox, i.e. in device memory.
+                // The host's other word (h_abort): 0 = carry on; 1 .. 2^31 - 1 = that many teams are asked to LEAVE (a launch beside the teams
+                // waits for a wave slot where the dispatcher put it; while the host waits for that launch it recycles no blocks, so the teams are
+                // all here: the first to look take a ticket each and go, the others carry on); above = hand out no more jobs.
+                {
                     const uint32_t t0 = (uint32_t)wall_clock64();
+                    uint32_t tried = 0u;
                     for (uint32_t spins = 1;; ++spins) {
-                        if (__hip_atomic_load(q.h_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > idx) break;
-                        if ((spins & 7u) == 0 && (__hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= 0x80000000u || (uint32_t)wall_clock64() - t0 > 4000000000u)) { idx = 0xFFFFFFFFu; break; }
+                        const uint32_t ab = __hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (ab >= 0x80000000u) break;
+                        if (ab > tried) { tried = ab; if (atomicAdd(q.next + 16, 1u) < ab) break; atomicSub(q.next + 16, 1u); }
+                        const uint32_t nx = __hip_atomic_load(q.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (nx >= q.n_jobs) break;
+                        const uint32_t ready = __hip_atomic_load(q.h_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (ready > nx) {
+                            idx = atomicAdd(q.next, 1u);
+                            if (idx >= q.n_jobs) { idx = 0xFFFFFFFFu; break; }
+                            // (another team took job nx in between: this one's block may not be free yet — wait for it, holding the job)
+                            for (uint32_t sp2 = 1; __hip_atomic_load(q.h_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) <= idx; ++sp2) {
+                                if ((sp2 & 7u) == 0 && (__hip_atomic_load(q.h_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= 0x80000000u || (uint32_t)wall_clock64() - t0 > 4000000000u)) { idx = 0xFFFFFFFFu; break; }
+                                for (int k = 0; k < 6; ++k) __builtin_amdgcn_s_sleep(127);
+                            }
+                            break;
+                        }
+                        if ((uint32_t)wall_clock64() - t0 > 4000000000u) break;
                         for (int k = 0; k < 6; ++k) __builtin_amdgcn_s_sleep(127);      // ~20 us between two looks
                     }
                 }

@@ -108,7 +108,7 @@ def test_fill_kernels_use_no_scratch_and_spill_no_vgpr(local16, tmp_path):
     assert len(one) == 4 and all(x["VGPRs"] <= 256 and x["VGPRs Spill"] <= 4 for x in one), one
     assert all(x["Occupancy"] == 2 for x in one)        # two waves per SIMD: eight waves of 256 registers fill a CU's register file
     four = [v for k, v in res.items() if "fill_regs_kernelILi4" in k]
-    assert len(four) == 4 and all(x["VGPRs Spill"] <= 8 for x in four), four   # (more than 64 contigs: three more granule registers per lane)
+    assert len(four) == 4 and all(x["VGPRs Spill"] <= 16 for x in four), four   # (more than 64 contigs: three more granule registers per lane; the one-bit-record instances a few more)
     # Round 4: the instances of the headline workload and the kernels launched beside resident teams use NO scratch memory at all.  The persistent teams stay resident for a whole call while the host launches
     # the fix-up / walk kernels and copies beside them; measured on the MI355X, a resident kernel WITH a scratch allocation held every
     # other launch and copy of the process back until its waves left (gpurun_out/r4f, r4g: walks of 7-40 s, copies of 39 s), one without

@@ -2,7 +2,7 @@
 # the final tree: the whole GPU suite, then the profiles of tag r04_b again (kernel sources changed since), the configurations' lines, four bench processes in a row
 set -o pipefail
 O=gpurun_out/collect_r04_b; mkdir -p $O
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee gpurun_out/r04_final_suite.txt || exit 1
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r04_final_suite.txt 2>&1; rc=$?; tail -3 gpurun_out/r04_final_suite.txt; [ $rc -eq 0 ] || exit 1
 bash profiles/collect.sh r04_b > gpurun_out/r04b_collect.log 2>&1; echo "collect rc $?"; tail -1 gpurun_out/r04b_collect.log | cut -c1-200
 bash profiles/collect_cmd.sh r04_b cfg5 python3 tests/config_runs.py --config cfg5 --reads 36 --batch 36 > gpurun_out/r04b_cfg5.log 2>&1; echo "cfg5 rc $?"
 {
