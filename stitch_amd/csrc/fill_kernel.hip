@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) void fixup_walk_kernel(const JobView* __restric
             const uint32_t r = pick_primary(V);
             uint32_t kr = 0;
             for (uint32_t k = 0; k < V.nact; ++k) if (V.act[k] == r) kr = k;
-            for (uint32_t e = (uint32_t)lane; e < V.n + 2; e += 64) { VisitRec z; z.contig = e == 0 ? (uint16_t)kr : (uint16_t)0xFFFFu; z.row = 0; z.layer = 0xFFFFFFFFu; z.nops = 0; z.nonspecial = 0; V.visit[e] = z; }
+            for (uint32_t e = (uint32_t)lane; e < V.n + 2; e += 64) V.visit[e] = JoinRole::cleared(e, kr);
             __syncthreads();
             ChainHdr H;
             WaveWalk ex; ex.lane = lane; ex.role = 1; ex.ref_slot = kr;

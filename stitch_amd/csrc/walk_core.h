@@ -430,22 +430,20 @@ STITCH_HD void walk_from_t(const JobView& V, uint32_t contig_index, ChainHdr& H,
 }
 STITCH_HD void walk_from(const JobView& V, uint32_t contig_index, ChainHdr& H, OpRec* ops, uint32_t ops_cap) { walk_from_t(V, contig_index, H, ops, ops_cap, SoloWalk()); }
 
-#if defined(__HIPCC__)
-// One wavefront, one walk: every lane carries the same state (walk_core.h, walk_from_t), lane 0 writes.
+// What a walk of traceback_all that may join the read's reference chain keeps and decides — the same on the device (WaveWalk below: a
+// wavefront per walk, lane 0 writes) and in the CPU emulation of the tests (tests/emu: one thread).
 // role 0: a plain walk.  role 1: the reference walk of traceback_all, which records its state on entering every column (VisitRec).
 // role 2: another walk of the same read, which stops where it enters a column in the recorded state.
-struct WaveWalk {
-    int lane;
+struct JoinRole {
     int role = 0; uint32_t ref_slot = 0; const ChainHdr* ref_hdr = nullptr;
     mutable bool met = false; mutable uint32_t met_nops = 0, met_nonspecial = 0;
-    __device__ bool writer() const { return lane == 0; }
-    __device__ bool joined() const { return met; }
-    __device__ uint32_t join_nops() const { return met_nops; }
-    __device__ uint32_t join_nonspecial() const { return met_nonspecial; }
-    __device__ ChainHdr reference_header() const { return *ref_hdr; }
-    __device__ static uint32_t layer_word(uint32_t layer, bool yfirst) { return layer | (yfirst ? 0x100u : 0u); }
-    __device__ bool enter_column(const JobView& V, uint32_t cur, uint32_t i, uint32_t j, uint32_t layer, uint32_t nops, uint32_t nonspecial, bool yfirst) const {
-        if (role == 1) { if (lane == 0) { VisitRec r; r.contig = (uint16_t)cur; r.row = (uint16_t)i; r.layer = layer_word(layer, yfirst); r.nops = nops; r.nonspecial = nonspecial; V.visit[j + 1] = r; } return false; }
+    STITCH_HD bool joined() const { return met; }
+    STITCH_HD uint32_t join_nops() const { return met_nops; }
+    STITCH_HD uint32_t join_nonspecial() const { return met_nonspecial; }
+    STITCH_HD ChainHdr reference_header() const { return *ref_hdr; }
+    STITCH_HD static uint32_t layer_word(uint32_t layer, bool yfirst) { return layer | (yfirst ? 0x100u : 0u); }
+    STITCH_HD bool enter_column_as(bool writes, const JobView& V, uint32_t cur, uint32_t i, uint32_t j, uint32_t layer, uint32_t nops, uint32_t nonspecial, bool yfirst) const {
+        if (role == 1) { if (writes) { VisitRec r; r.contig = (uint16_t)cur; r.row = (uint16_t)i; r.layer = layer_word(layer, yfirst); r.nops = nops; r.nonspecial = nonspecial; V.visit[j + 1] = r; } return false; }
         // (never in column 0: a walk gets there through its prefix clips, which have set ITS start coordinates already — two chains that
         // start in the same contig at different cells both arrive at (contig, row 0, column 0, start), and the one is not the other's prefix)
         if (role != 2 || yfirst || j == 0) return false;
@@ -453,10 +451,23 @@ struct WaveWalk {
         if (r.contig == (uint16_t)cur && r.row == (uint16_t)i && r.layer == layer_word(layer, false)) { met = true; met_nops = r.nops; met_nonspecial = r.nonspecial; return true; }
         return false;
     }
-    __device__ void finish_reference(const JobView& V, uint32_t nops, uint32_t nonspecial, bool usable) const {
-        if (role != 1 || lane != 0) return;
+    STITCH_HD void finish_reference_as(bool writes, const JobView& V, uint32_t nops, uint32_t nonspecial, bool usable) const {
+        if (role != 1 || !writes) return;
         VisitRec r; r.contig = (uint16_t)ref_slot; r.row = usable ? 1 : 0; r.layer = 0; r.nops = nops; r.nonspecial = nonspecial; V.visit[0] = r;
     }
+    // the records as the reference walk finds them: nothing matches, entry 0 names the reference chain's slot and says "not usable" yet
+    STITCH_HD static VisitRec cleared(uint32_t entry, uint32_t ref_slot_) { VisitRec z; z.contig = entry == 0 ? (uint16_t)ref_slot_ : (uint16_t)0xFFFFu; z.row = 0; z.layer = 0xFFFFFFFFu; z.nops = 0; z.nonspecial = 0; return z; }
+};
+
+#if defined(__HIPCC__)
+// One wavefront, one walk: every lane carries the same state (walk_core.h, walk_from_t), lane 0 writes.
+struct WaveWalk : JoinRole {
+    int lane;
+    __device__ bool writer() const { return lane == 0; }
+    __device__ bool enter_column(const JobView& V, uint32_t cur, uint32_t i, uint32_t j, uint32_t layer, uint32_t nops, uint32_t nonspecial, bool yfirst) const {
+        return enter_column_as(lane == 0, V, cur, i, j, layer, nops, nonspecial, yfirst);
+    }
+    __device__ void finish_reference(const JobView& V, uint32_t nops, uint32_t nonspecial, bool usable) const { finish_reference_as(lane == 0, V, nops, nonspecial, usable); }
     // Cells (i-l, j-l), l = 0..63, fetched by lane l.  Returns the number L of leading cells that are plain diagonal steps
     // (traceback code MV_DIAG: source = the cell up-left in the same contig) with row >= 2 and 1 <= column < n (row 1 can
     // hold the circular jump, column n the fix-up overrides: both stay on the literal path); their operations are written

@@ -326,7 +326,8 @@ void* emu_ctx_new(const int32_t* params, uint32_t C, const char* const* names, c
 void emu_ctx_free(void* h) { delete (EmuCtx*)h; }
 
 // Runs one DP job and writes chains in the oracle's wire format, concatenated; returns the number of chains or <0.
-// mode 0: traceback, 1: one chain per active contig (status None => n_ops = -1 marker), 2: traceback_from(from)
+// mode 0: traceback, 1: one chain per active contig (status None => n_ops = -1 marker), 2: traceback_from(from), 3: as 1 with the walks JOINED to the
+// reference chain the way the device does it (walk_core.h JoinRole)
 long emu_job(void* h, const uint8_t* y, uint32_t n, const uint32_t* act, uint32_t nact, int mode, uint32_t from, int64_t* out, size_t cap,
              size_t* used, int local16) {
     const EmuCtx& X = *(EmuCtx*)h;
@@ -349,7 +350,7 @@ long emu_job(void* h, const uint8_t* y, uint32_t n, const uint32_t* act, uint32_
     V.jt_from = J.jtf.data(); V.Ival = J.Ival.data(); V.Ilen = J.Ilen.data(); V.SmoveF = J.SmoveF.data(); V.SidxF = J.SidxF.data();
     V.SfromF = J.SfromF.data(); V.ImoveF = J.ImoveF.data(); V.Smove0 = X.Smove0.data(); V.Imove0 = X.Imove0.data(); V.Slen0 = X.Slen0.data();
     V.Sm = J.Sm.data(); V.Lm = J.Lm.data();
-    V.tb_keyfmt = local16 ? 1u : 0u;
+    V.tb_keyfmt = local16 ? 1u : 0u; V.visit = nullptr; V.Wcol = nullptr;
     try { if (local16) emu_fill_local(X, J); else emu_fill(X, J); }
     catch (const std::exception& e) { fprintf(stderr, "emu: %s\n", e.what()); return -3; }
     for (uint32_t k = 0; k < nact; ++k) fixup_contig(V, act[k]);
@@ -367,7 +368,53 @@ long emu_job(void* h, const uint8_t* y, uint32_t n, const uint32_t* act, uint32_
         if (H.status == 1) out[o + 10] = -1;       // mode slot marks None
         o += need; ++nch; return true;
     };
-    if (mode == 1) { for (uint32_t k = 0; k < nact; ++k) if (!emit(act[k])) return -2; }
+    if (mode == 3) {
+        // traceback_all with JOINED walks, as fixup_walk_kernel + walk_all_kernel + download_chains do it (walk_core.h JoinRole): the chain from
+        // the best end contig is walked first and records its state on entering every column; every other walk stops where it enters a column
+        // in the recorded state, and its chain is the reference chain's first join_ops operations followed by its own
+        struct JoinSolo : JoinRole {
+            bool writer() const { return true; }
+            uint32_t diag_run(const JobView&, uint32_t, uint32_t, uint32_t, uint32_t, OpRec*, uint32_t, uint32_t, bool) const { return 0; }
+            bool enter_column(const JobView& V_, uint32_t cur, uint32_t i, uint32_t j, uint32_t layer, uint32_t nops, uint32_t nonspecial, bool yfirst) const {
+                return enter_column_as(true, V_, cur, i, j, layer, nops, nonspecial, yfirst);
+            }
+            void finish_reference(const JobView& V_, uint32_t nops, uint32_t nonspecial, bool usable) const { finish_reference_as(true, V_, nops, nonspecial, usable); }
+            void reverse(OpRec* o_, uint32_t nops) const { for (uint32_t a = 0, b = nops; a + 1 < b; ++a, --b) { OpRec t = o_[a]; o_[a] = o_[b - 1]; o_[b - 1] = t; } }
+        };
+        const uint32_t r = pick_primary(V);
+        uint32_t kr = 0; for (uint32_t k = 0; k < nact; ++k) if (act[k] == r) kr = k;
+        std::vector<VisitRec> visit(n + 2);
+        for (uint32_t e = 0; e < n + 2; ++e) visit[e] = JoinRole::cleared(e, kr);
+        V.visit = visit.data();
+        std::vector<ChainHdr> hdr(nact); std::vector<std::vector<OpRec>> opsv(nact, std::vector<OpRec>(ops_cap));
+        { JoinSolo ex; ex.role = 1; ex.ref_slot = kr; walk_from_t(V, r, hdr[kr], opsv[kr].data(), ops_cap, ex); }
+        for (uint32_t k = 0; k < nact; ++k) {
+            if (k == kr) continue;
+            JoinSolo ex;
+            if (visit[0].row == 1) { ex.role = 2; ex.ref_hdr = &hdr[kr]; }
+            walk_from_t(V, act[k], hdr[k], opsv[k].data(), ops_cap, ex);
+        }
+        for (uint32_t k = 0; k < nact; ++k) {
+            ChainHdr H = hdr[k];
+            if (H.status == 4) H.status = 1;
+            if (H.status >= 2) return -2;
+            std::vector<OpRec> whole;
+            if (H.status == 1) { H.n_ops = 0; H.score = MIN_SCORE; }
+            else if (H.join_ops) {
+                if (H.join_slot != kr || H.join_ops > hdr[kr].n_ops) return -4;
+                whole.assign(opsv[kr].begin(), opsv[kr].begin() + H.join_ops);
+                whole.insert(whole.end(), opsv[k].begin(), opsv[k].begin() + H.n_ops);
+                H.n_ops = (uint32_t)whole.size();
+            }
+            else whole.assign(opsv[k].begin(), opsv[k].begin() + H.n_ops);
+            size_t need = put_chain(H, whole.data(), out + o, cap > o ? cap - o : 0);
+            if (o + need > cap) return -2;
+            if (H.status == 1) out[o + 10] = -1;
+            o += need; ++nch;
+        }
+        V.visit = nullptr;
+    }
+    else if (mode == 1) { for (uint32_t k = 0; k < nact; ++k) if (!emit(act[k])) return -2; }
     else if (!emit(mode == 0 ? pick_primary(V) : from)) return -2;
     (void)undefined;   // chains the reference cannot define are reported as None; the tests skip them when the oracle throws
     if (used) *used = o;

@@ -40,7 +40,7 @@ class Emu:
     def job(self, y, act=None, mode=0, frm=0, local16=False):
         y = y.encode() if isinstance(y, str) else bytes(y)
         act = list(range(self.C)) if act is None else sorted(act)
-        cap = 64 + (len(act) if mode == 1 else 1) * (12 + 3 * ((len(y) + 1) * (max(len(b) for b in self._bufs) + 2) + 64))
+        cap = 64 + (len(act) if mode in (1, 3) else 1) * (12 + 3 * ((len(y) + 1) * (max(len(b) for b in self._bufs) + 2) + 64))
         out = (C.c_int64 * cap)()
         used = C.c_size_t(0)
         n = lib().emu_job(self.h, (C.c_uint8 * len(y)).from_buffer_copy(y), len(y), (C.c_uint32 * len(act))(*act), len(act), mode, frm,

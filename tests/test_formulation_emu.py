@@ -158,6 +158,34 @@ def compare_case(p, contigs, y, rng):
             assert g.key() == w.key(), f"from {c}\nwant {w}\ngot  {g}\nparams {p}\ncontigs {contigs}\ny {y} subset {subset}"
 
 
+    # ... and the same candidates when the walks JOIN the reference chain the way the device's do (walk_core.h JoinRole: emu mode 3)
+    joined = emu.job(y, subset, 3)
+    assert [None if c is None else c.key() for c in joined] == [None if c is None else c.key() for c in cands], \
+        f"joined walks\nparams {p}\ncontigs {contigs}\ny {y} subset {subset}"
+
+
+def test_joined_walks_keep_their_own_start_when_they_meet_the_reference_chain_in_column_0():
+    """two chains that start in the same contig at different cells both arrive at (contig, row 0, column 0, start) once their prefix clips
+    are done: the second must not take the first one's start coordinates (found on the device by tests/gpu_fuzz.py FUZZ_STREAM=1, seed
+    7087; here the same read and contigs through the CPU emulation)"""
+    import os
+    os.environ["FUZZ_STREAM"] = "1"
+    try:
+        from tests import gpu_fuzz as G
+        targets, reads, opts, _, _, lens = G.draw(7087)
+    finally:
+        del os.environ["FUZZ_STREAM"]
+    assert lens == [34, 1453, 5, 29] and opts == dict(double_strand=True, circular=True, suboptimal=True)
+    contigs = [(n, True, s) for n, s in targets] + [(n, False, rc(s)) for n, s in targets]
+    p = params(1, -4, -6, -2, -10, -10, -10, "local", True)
+    emu = Emu(p, contigs)
+    y = reads[11]
+    plain, joined = emu.job(y, None, 1), emu.job(y, None, 3)
+    assert [c.key() for c in joined] == [c.key() for c in plain]
+    ref = max(plain, key=lambda c: c.score)
+    assert any(c.start_contig_idx == ref.start_contig_idx and (c.xstart, c.ystart) != (ref.xstart, ref.ystart) for c in plain)      # (the situation is there)
+
+
 @pytest.mark.parametrize("seed", range(400))
 def test_random_small(seed):
     rng = random.Random(seed)
