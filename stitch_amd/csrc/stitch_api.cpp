@@ -534,25 +534,28 @@ int pick_waves(const stitch_ctx& c, uint32_t nact, int maxw) {          // fewes
 // (the teams leave after the read they are on, the stuck launch then runs) and what is left goes launch by launch.
 static int bounded_sync(stitch_ctx& c, hipStream_t s) {
     if (!c.stream_abort_word) { HIP_TRY(hipStreamSynchronize(s)); return STITCH_OK; }
-    // After a quarter of a second teams are asked to LEAVE: one, then (a tenth of a second later each) three and eight in all, never the
-    // last one.  While the host waits here it recycles no arena blocks, so after the few spare blocks are used up every team is waiting for
-    // one and looks at the host's words every 20 us: the first to look take the tickets and return, their wave slots are free, the stuck
-    // workgroup runs, and the call goes on with the teams that are left.  Only if the launch still does not end a second after the last
-    // ticket is the whole run called off.
+    // The stuck workgroup waits for a slot in ONE shader engine; a team's 50 waves sit in six or seven of the chip's 32.  After a quarter of
+    // a second ONE team is asked to leave (while the host waits here it recycles no arena blocks, so after the few spare ones are used up
+    // every team is waiting for a block and looks at the host's words every 20 us: the first to look takes the ticket and returns) — that
+    // costs a fortieth of the call's rate and frees the right engine about one time in five (seen: the walk ran 6 ms after the ticket).
+    // More tickets cost more than they are worth (eight teams gone, and the launch still stuck, has been seen too): 30 ms after the ticket —
+    // a waiting team takes it within microseconds, the freed slots are taken within milliseconds or not at all —
+    // the run is called off — every team leaves, waiting ones at once — and what is left goes launch by launch, 5 % below the teams' rate.
     auto t0 = std::chrono::steady_clock::now();
+    bool ticket_here = false;                    // (this wait has asked a team to leave: the clock runs from the ticket)
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
         if (e == hipSuccess) return STITCH_OK;
         if (e != hipErrorNotReady) return fail(STITCH_EDEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e));
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        const uint32_t next_tickets = std::min<uint32_t>(c.stream_may_retire, c.stream_retired == 0 ? 1u : c.stream_retired < 3u ? 3u : 8u);
-        if (!c.stream_stalled && (c.knobs.test_stream_stall || (next_tickets <= c.stream_retired && waited > 1.0))) {
+        const uint32_t next_tickets = std::min<uint32_t>(c.stream_may_retire, 1u);
+        if (!c.stream_stalled && (c.knobs.test_stream_stall || (next_tickets <= c.stream_retired && waited > (ticket_here ? 0.03 : c.stream_bound_s)))) {
             c.stream_stalled = true;
             *(volatile uint32_t*)c.stream_abort_word = 0xFFFFFFFFu;
             std::atomic_thread_fence(std::memory_order_seq_cst);
         }
         else if (!c.stream_stalled && next_tickets > c.stream_retired && (waited > (c.stream_retired == 0 ? c.stream_bound_s : 0.1) || (c.knobs.test_stream_retire && c.stream_retired == 0))) {
-            c.tm.teams_retired += next_tickets - c.stream_retired; c.stream_retired = next_tickets;
+            c.tm.teams_retired += next_tickets - c.stream_retired; c.stream_retired = next_tickets; ticket_here = true;
             *(volatile uint32_t*)c.stream_abort_word = c.stream_retired;
             std::atomic_thread_fence(std::memory_order_seq_cst);
             if (c.knobs.trace) fprintf(stderr, "[trace] a launch beside the teams has waited %.0f ms: %u team(s) in all asked to leave\n", waited * 1e3, c.stream_retired);
@@ -843,7 +846,7 @@ static int run_jobs_streaming(stitch_ctx& c, std::vector<Job>& jobs, bool* handl
     HIP_TRY(hipStreamSynchronize(sB));
     c.tm.h2d_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h2d0).count();
     if (const char* e = getenv("STITCH_STREAM_SETTLE_MS")) { HIP_TRY(hipDeviceSynchronize()); std::this_thread::sleep_for(std::chrono::milliseconds(atoi(e))); }      // (experiment)
-    c.stream_abort_word = c.pin_q + 16; c.stream_stalled = false; c.stream_retired = 0; c.stream_may_retire = (uint32_t)std::min<size_t>(8, T > 0 ? T - 1 : 0);
+    c.stream_abort_word = c.pin_q + 16; c.stream_stalled = false; c.stream_retired = 0; c.stream_may_retire = (uint32_t)std::min<size_t>(1, T > 0 ? T - 1 : 0);
     if (const char* e = getenv("STITCH_STREAM_BOUND_MS")) c.stream_bound_s = std::max(1, atoi(e)) * 1e-3;
     hq[0] = (uint32_t)std::min(N, B);                  // the first B jobs find their blocks free
     std::atomic_thread_fence(std::memory_order_seq_cst);
