@@ -83,64 +83,62 @@ def test_cfg2_constructed_reads_known_answers(launch):
         assert recompute_score(ch[0].operations) == ch[0].score
 
 
-def test_cfg2_reads_of_the_launch_equal_the_oracle_at_full_size(launch):
+MODES = ["global", "query-local", "target-local"]
+
+
+@pytest.fixture(scope="module")
+def oracle_wave(launch):
+    """The oracle's answers for everything this module compares at full size, computed SIDE BY SIDE (a read is 40 GB of 16-byte cells and
+    about two minutes on one core; ctypes releases the GIL: one aligner set per thread): two chimeric reads of the Local-mode launch, and
+    one read per non-Local mode.  Five at once are 187 GiB of cells — the box's share of host memory allows that, not seven."""
     db, reads, al, res, tm = launch
     avail = mem_available()
-    workers = int(min(4, (avail * 0.8) // (ORACLE_BYTES_PER_READ + (2 << 30))))
+    workers = int(min(5, (avail * 0.8) // (ORACLE_BYTES_PER_READ + (2 << 30))))
     if workers < 1:
         pytest.skip(f"the oracle needs {ORACLE_BYTES_PER_READ / 2**30:.0f} GiB per read, {avail / 2**30:.0f} GiB available")
     targets = [(n, s.decode()) for n, s in db]
-    # first reads of the stream that are chimeric (more than one chain segment), plus the slot the duplicate shares
-    picks = [k for k in range(60) if any(o[0] == 6 for o in res[k][0][0].operations)][:max(2, workers)]
+    # first reads of the stream that are chimeric (more than one chain segment)
+    picks = [k for k in range(60) if any(o[0] == 6 for o in res[k][0][0].operations)][:2]
     if len(picks) < 2:
         picks = [0, 1]
-    picks = picks[:max(2, workers)]
+    mode_reads = [r for r in reads[:8] if r != reads[0]][:len(MODES)]
+    jobs = [("local", k, reads[k], f"read_{k:07d}") for k in picks] + [(m, None, r, "read_0000000") for m, r in zip(MODES, mode_reads)]
 
-    def oracle_read(k):
-        o = orc.Aligners(targets)
-        want = o.align(reads[k])
-        sam = o.format_sam(f"read_{k:07d}", reads[k].decode(), "I" * N)
-        return k, [c.key() for c in want], sam
+    def oracle_read(job):
+        mode, k, read, name = job
+        o = orc.Aligners(targets) if mode == "local" else orc.Aligners(targets, mode=mode)
+        want = o.align(read)
+        return mode, k, [c.key() for c in want], o.format_sam(name, read.decode(), "I" * N)
 
-    with ThreadPoolExecutor(max_workers=workers) as ex:          # ctypes releases the GIL: one aligner set per thread
-        results = list(ex.map(oracle_read, picks))
-    for k, want_keys, want_sam in results:
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        answers = list(ex.map(oracle_read, jobs))
+    return answers, dict(zip(MODES, mode_reads))
+
+
+def test_cfg2_reads_of_the_launch_equal_the_oracle_at_full_size(launch, oracle_wave):
+    db, reads, al, res, tm = launch
+    answers, _ = oracle_wave
+    local = [a for a in answers if a[0] == "local"]
+    for _, k, want_keys, want_sam in local:
         got = res[k][0]
         assert [c.key() for c in got] == want_keys, f"read {k} differs from the oracle at n = {N}"
         assert al.format_sam(k, f"read_{k:07d}", reads[k], b"I" * N) == want_sam, f"SAM text of read {k}"
-    assert len(results) >= 2
+    assert len(local) >= 2
 
 
-def test_cfg2_size_reads_in_the_other_clipping_modes_equal_the_oracle():
+def test_cfg2_size_reads_in_the_other_clipping_modes_equal_the_oracle(launch, oracle_wave):
     """One 10 kb read per non-Local mode against the 50 x 5 kb contigs, through the 32-bit register-resident kernel
     (fill_regs32.hip: scores of these modes leave the 16-bit range), chains, operation lists and SAM text compared with the oracle at
     full size (aligners/constants.rs:96-136 for the modes' clip penalties, single_contig_aligner.rs:453-470 for the end-of-read jump)."""
-    modes = ["global", "query-local", "target-local"]
-    avail = mem_available()
-    workers = int(min(len(modes), (avail * 0.8) // (ORACLE_BYTES_PER_READ + (2 << 30))))
-    if workers < 1:
-        pytest.skip(f"the oracle needs {ORACLE_BYTES_PER_READ / 2**30:.0f} GiB per read, {avail / 2**30:.0f} GiB available")
-    db = synth.make_db(CONTIGS, M, 1001)
-    reads = synth.make_reads(db, 8, N, 44)
-    chimeric = [r for r in reads if r != reads[0]][:len(modes)]
-    targets = [(n, s.decode()) for n, s in db]
-    got = {}
-    for mode, read in zip(modes, chimeric):
+    db = launch[0]
+    answers, mode_reads = oracle_wave
+    for mode, _, want_keys, want_sam in [a for a in answers if a[0] != "local"]:
+        read = mode_reads[mode]
         al = stitch_amd.Builder(mode=mode).build_aligners([stitch_amd.TargetSeq(n, s) for n, s in db])
         res = al.align([read])
         tm = al.timing()
         assert tm["fill_kind"] == 3 and al.cells_filled == N * CONTIGS * M, (mode, tm)
-        got[mode] = ([c.key() for c in res[0][0]], al.format_sam(0, "read_0000000", read, b"I" * N))
+        assert [c.key() for c in res[0][0]] == want_keys, f"mode {mode}: chains differ from the oracle at n = {N}"
+        assert al.format_sam(0, "read_0000000", read, b"I" * N) == want_sam, f"mode {mode}: SAM text"
         del al
-
-    def oracle_read(item):
-        mode, read = item
-        o = orc.Aligners(targets, mode=mode)
-        want = o.align(read)
-        return mode, [c.key() for c in want], o.format_sam("read_0000000", read.decode(), "I" * N)
-
-    with ThreadPoolExecutor(max_workers=workers) as ex:
-        results = list(ex.map(oracle_read, zip(modes, chimeric)))
-    for mode, want_keys, want_sam in results:
-        assert got[mode][0] == want_keys, f"mode {mode}: chains differ from the oracle at n = {N}"
-        assert got[mode][1] == want_sam, f"mode {mode}: SAM text"
+    assert len([a for a in answers if a[0] != "local"]) == len(MODES)
